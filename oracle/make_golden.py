@@ -1,0 +1,233 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own vqvae.py on CPU.
+
+Runs only in the build container (needs /root/reference, read-only).  The
+reference never travels: only inputs-by-seed and its numeric outputs are stored.
+All inputs/weights come from oracle/rng.py so the fixtures hold outputs only.
+
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+REF = os.environ.get("VQ2_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+import vqvae as ref  # noqa: E402  (the reference module)
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import rng  # noqa: E402
+from oracle import vqvae_oracle as O  # noqa: E402
+from oracle.make_golden_cases import (BLOCK_CASES, CONV_FLAVOURS, SEED, block_state,  # noqa: E402
+                                      conv_inputs, quantize_inputs)
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def n(x):
+    return x.detach().cpu().numpy().copy()
+
+
+# ---------------------------------------------------------------- Quantize
+def quantize_case(tag, D, K, xshape, training, tie=False, store_full=True):
+    q = ref.Quantize(D, K)
+    x, embed, cs0, gw = quantize_inputs(tag, D, K, xshape, tie)
+    q.embed.copy_(t(embed))
+    q.embed_avg.copy_(t(embed) * t(cs0)[None, :])
+    q.cluster_size.copy_(t(cs0))
+    q.train(training)
+    xt = t(x).clone().requires_grad_(True)
+    out, diff, idx = q(xt)
+    loss = (out * t(gw)).sum() + 0.25 * diff
+    loss.backward()
+    d = {f"{tag}.idx": n(idx).astype(np.int32), f"{tag}.diff": n(diff)}
+    if store_full:
+        d.update({f"{tag}.out": n(out), f"{tag}.xgrad": n(xt.grad),
+                  f"{tag}.embed_after": n(q.embed), f"{tag}.cluster_size_after": n(q.cluster_size),
+                  f"{tag}.embed_avg_after": n(q.embed_avg)})
+    else:
+        d.update({f"{tag}.out_rows": n(out).reshape(-1, D)[::16],
+                  f"{tag}.xgrad_rows": n(xt.grad).reshape(-1, D)[::16],
+                  f"{tag}.cluster_size_after": n(q.cluster_size),
+                  f"{tag}.embed_after_cols": n(q.embed)[:, ::64]})
+    return d
+
+
+def gen_quantize():
+    d = {}
+    d.update(quantize_case("q512_train", 64, 512, (2, 8, 8, 64), True))
+    d.update(quantize_case("q512_eval", 64, 512, (2, 8, 8, 64), False))
+    d.update(quantize_case("q512_tie", 64, 512, (2, 8, 8, 64), True, tie=True))
+    d.update(quantize_case("q8192_train", 64, 8192, (2, 16, 16, 64), True, store_full=False))
+    d.update(quantize_case("q64_train", 16, 64, (2, 4, 4, 16), True))
+    np.savez_compressed(os.path.join(OUT, "quantize.npz"), **d)
+
+
+# ---------------------------------------------------------------- conv flavours
+def gen_convs():
+    import torch.nn.functional as F
+    d = {}
+    for tag, kind, ws, stride, pad, hw in CONV_FLAVOURS:
+        x, w, b = (t(a).requires_grad_(True) for a in conv_inputs(tag, kind, ws, hw))
+        if kind == "conv":
+            y = F.conv2d(x, w, b, stride=stride, padding=pad)
+        else:
+            y = F.conv_transpose2d(x, w, b, stride=stride, padding=pad)
+        gy = t(rng.normal(SEED, f"{tag}.gy", tuple(y.shape)))
+        y.backward(gy)
+        d[f"{tag}.y"] = n(y)
+        d[f"{tag}.gx"] = n(x.grad)
+        d[f"{tag}.gw"] = n(w.grad)
+        d[f"{tag}.gb"] = n(b.grad)
+    np.savez_compressed(os.path.join(OUT, "convs.npz"), **d)
+
+
+# ---------------------------------------------------------------- blocks
+def gen_blocks():
+    d = {}
+    for tag, kind, args, xs in BLOCK_CASES:
+        if kind == "resblock":
+            m = ref.ResBlock(*args)
+        elif kind == "encoder":
+            m = ref.Encoder(*args[:4], stride=args[4])
+        else:
+            m = ref.Decoder(*args[:5], stride=args[5])
+        st = block_state(tag, kind, args)
+        assert list(m.state_dict().keys()) == list(st.keys()), tag
+        m.load_state_dict(st)
+        x = t(rng.normal(SEED, f"{tag}.x", xs)).requires_grad_(True)
+        y = m(x)
+        gy = t(rng.normal(SEED, f"{tag}.gy", tuple(y.shape)))
+        y.backward(gy)
+        d[f"{tag}.y"] = n(y)
+        d[f"{tag}.gx"] = n(x.grad)
+        for k, p in m.named_parameters():
+            d[f"{tag}.g.{k}"] = n(p.grad)
+    np.savez_compressed(os.path.join(OUT, "blocks.npz"), **d)
+
+
+# ---------------------------------------------------------------- tiny VQVAE, 3 Adam steps
+def gen_tiny():
+    cfg = O.TINY
+    m = ref.VQVAE(channel=cfg.channel, n_res_block=cfg.n_res_block, n_res_channel=cfg.n_res_channel,
+                  embed_dim=cfg.embed_dim, n_embed=cfg.n_embed)
+    st = O.make_state(cfg, SEED)
+    assert list(m.state_dict().keys()) == list(st.keys())
+    m.load_state_dict(st)
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=3e-4)
+    d = {}
+    for step in range(3):
+        img = O.make_images(2, 32, SEED + 100 * step)
+        opt.zero_grad()
+        dec, diff = m(img)
+        recon = torch.nn.functional.mse_loss(dec, img)
+        latent = diff.mean()
+        loss = recon + 0.25 * latent
+        loss.backward()
+        if step == 0:
+            d["s0.dec"] = n(dec)
+            d["s0.diff"] = n(diff)
+            for k, p in m.named_parameters():
+                if p.grad is not None:
+                    d[f"s0.g.{k}"] = n(p.grad)
+            d["s0.nograd"] = np.array([k for k, p in m.named_parameters() if p.grad is None])
+        d[f"s{step}.loss"] = n(loss)
+        d[f"s{step}.recon"] = n(recon)
+        d[f"s{step}.latent"] = n(latent)
+        opt.step()
+        if step in (0, 2):
+            for k, v in m.state_dict().items():
+                if not k.startswith("dec_ir."):
+                    d[f"s{step}.after.{k}"] = n(v)
+    # ids of step 0: fresh model, same weights, eval mode (indices do not depend on the mode)
+    m2 = ref.VQVAE(channel=cfg.channel, n_res_block=cfg.n_res_block, n_res_channel=cfg.n_res_channel,
+                   embed_dim=cfg.embed_dim, n_embed=cfg.n_embed)
+    m2.load_state_dict(O.make_state(cfg, SEED))
+    m2.eval()
+    with torch.no_grad():
+        qt, qb, diff, id_t, id_b = m2.encode(O.make_images(2, 32, SEED))
+    d["s0.id_t"] = n(id_t).astype(np.int32)
+    d["s0.id_b"] = n(id_b).astype(np.int32)
+    d["s0.quant_t"] = n(qt)
+    d["s0.quant_b"] = n(qb)
+    d["eval.diff"] = n(diff)
+    np.savez_compressed(os.path.join(OUT, "tiny_vqvae.npz"), **d)
+
+
+# ---------------------------------------------------------------- config 1 (single level)
+def gen_single_level():
+    cfg = O.DEFAULT
+    st = O.make_single_level_state(cfg, SEED)
+    enc = ref.Encoder(3, 128, 2, 32, stride=4)
+    qconv = torch.nn.Conv2d(128, 64, 1)
+    quant = ref.Quantize(64, 512)
+    dec = ref.Decoder(64, 3, 128, 2, 32, stride=4)
+    enc.load_state_dict({k[4:]: v for k, v in st.items() if k.startswith("enc.")})
+    qconv.load_state_dict({k[len("quantize_conv."):]: v for k, v in st.items() if k.startswith("quantize_conv.")})
+    quant.load_state_dict({k[len("quantize."):]: v for k, v in st.items() if k.startswith("quantize.")})
+    dec.load_state_dict({k[4:]: v for k, v in st.items() if k.startswith("dec.")})
+    img = O.make_images(16, 32, SEED)
+    h = qconv(enc(img)).permute(0, 2, 3, 1)
+    q, diff, idx = quant(h)
+    out = dec(q.permute(0, 3, 1, 2))
+    recon = torch.nn.functional.mse_loss(out, img)
+    loss = recon + 0.25 * diff
+    loss.backward()
+    d = {"dec": n(out)[:2], "diff": n(diff), "idx": n(idx).astype(np.int32), "loss": n(loss),
+         "recon": n(recon)}
+    for name, mod in (("enc", enc), ("quantize_conv", qconv), ("dec", dec)):
+        for k, p in mod.named_parameters():
+            d[f"gnorm.{name}.{k}"] = n(p.grad.norm())
+    d["cluster_size_after"] = n(quant.cluster_size)
+    np.savez_compressed(os.path.join(OUT, "single_level.npz"), **d)
+
+
+# ---------------------------------------------------------------- full-size 256^2, B=2
+def gen_full256():
+    cfg = O.DEFAULT
+    m = ref.VQVAE()
+    m.load_state_dict(O.make_state(cfg, SEED))
+    m.train()
+    img = O.make_images(2, 256, SEED)
+    # ids via hooks on the two Quantize modules
+    ids = {}
+    m.quantize_t.register_forward_hook(lambda mod, i, o: ids.__setitem__("t", o[2]))
+    m.quantize_b.register_forward_hook(lambda mod, i, o: ids.__setitem__("b", o[2]))
+    dec, diff = m(img)
+    recon = torch.nn.functional.mse_loss(dec, img)
+    loss = recon + 0.25 * diff.mean()
+    loss.backward()
+    d = {"id_t": n(ids["t"]).astype(np.int16), "id_b": n(ids["b"]).astype(np.int16),
+         "diff": n(diff), "recon": n(recon), "loss": n(loss),
+         "dec_sample": n(dec)[:, :, ::16, ::16]}
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            d[f"gnorm.{k}"] = n(p.grad.norm())
+    d["cluster_size_t_after"] = n(m.quantize_t.cluster_size)
+    d["cluster_size_b_after"] = n(m.quantize_b.cluster_size)
+    np.savez_compressed(os.path.join(OUT, "full256.npz"), **d)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    which = sys.argv[1:] or ["quantize", "convs", "blocks", "tiny", "single", "full"]
+    if "quantize" in which:
+        gen_quantize()
+    if "convs" in which:
+        gen_convs()
+    if "blocks" in which:
+        gen_blocks()
+    if "tiny" in which:
+        gen_tiny()
+    if "single" in which:
+        gen_single_level()
+    if "full" in which:
+        gen_full256()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
