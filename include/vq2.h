@@ -1,0 +1,162 @@
+/*
+ * vq2.h -- C ABI of libvq2.so: the MI355X (gfx950) implementation of the
+ * VQ-VAE-2 stage-1 hot path of alehdaghi/vq-vae-2-pytorch.
+ *
+ * The reference has NO native/FFI boundary on this path: every op
+ * in vqvae.py is an ATen call made from Python.  Each entry point below therefore
+ * cites the reference *Python call site* (file:line under /root/reference) whose
+ * ATen kernel it replaces.  The host-side mirror of the reference's nn.Module
+ * interface lives in vq-vae-2-pytorch_amd/vqvae.py and calls these through ctypes.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32 unless stated; the caller owns all
+ *    memory (tensors and workspaces); the library allocates nothing persistent.
+ *  - activations are NHWC: element (n,h,w,c) at ((n*H+h)*W+w)*ld + c where the
+ *    pixel stride ld >= C lets an op read/write a channel slice of a wider buffer
+ *    (that is how torch.cat at vqvae.py:233 and :218 disappears).
+ *    Channel counts and pixel strides must be multiples of 4 (16-byte vectors).
+ *  - `stream` is a hipStream_t (NULL = default stream).  All work is enqueued on
+ *    it; no entry point synchronises the device.
+ *  - return value: VQ2_OK or an error class; vq2_last_error() returns the
+ *    message of the calling thread's last failure (thread-local, re-entrant:
+ *    forward runs on the main thread, backward on an autograd thread).
+ */
+#ifndef VQ2_H
+#define VQ2_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VQ2_OK 0
+#define VQ2_ERR_INVALID 1     /* bad argument (shape, alignment, null pointer)  */
+#define VQ2_ERR_UNSUPPORTED 2 /* valid but not implemented configuration        */
+#define VQ2_ERR_WORKSPACE 3   /* workspace too small                            */
+#define VQ2_ERR_LAUNCH 4      /* hipLaunch / runtime error                      */
+
+typedef void *vq2_stream_t;
+
+int vq2_version(void);
+const char *vq2_last_error(void);
+
+/* ------------------------------------------------------------------ conv
+ * One descriptor describes the FORWARD op; fwd/dgrad/wgrad entry points all
+ * take the same descriptor so callers never swap roles by hand.
+ *   conv  (transposed=0): y[N,Ho,Wo,Co] = conv2d(x[N,H,W,Ci], w[Co,Ci,KH,KW], stride, pad)
+ *                         Ho = (H+2*pad-KH)/stride+1            (vqvae.py:87,89,105-116,137,184,189)
+ *   convT (transposed=1): y[N,2H,2W,Co] = conv_transpose2d(x, w[Ci,Co,4,4], stride 2, pad 1)
+ *                                                               (vqvae.py:150-160,191-193)
+ */
+typedef struct vq2_conv_desc {
+    int32_t N, H, W, Ci; /* input, NHWC                                         */
+    int32_t Co;          /* output channels                                     */
+    int32_t KH, KW, stride, pad;
+    int32_t transposed;  /* 0 conv, 1 conv-transpose (KH=KW=4, stride 2, pad 1) */
+    int32_t ldx, ldy;    /* pixel strides of x and y buffers (elements)         */
+    int32_t Cir, Cor;    /* channel counts of the reference weight/bias tensors (<= Ci, Co; 0 = same).
+                            Ci/Co are rounded up to a multiple of 4 (the 3-channel image and
+                            reconstruction, vqvae.py:105,157); padded channels read as weight 0,
+                            are written as 0 and are skipped in dw/db. */
+} vq2_conv_desc;
+
+/* epilogue / prologue fusion flags */
+#define VQ2_RELU_IN 1  /* operand is relu(x): ReLU fused into the load (vqvae.py:86,88,107,...) */
+#define VQ2_RELU_OUT 2 /* y = relu(...): trailing in-place ReLU (vqvae.py:122,144)            */
+
+/* weight packing: reference layouts (OIHW for Conv2d, IOHW for ConvTranspose2d,
+ * i.e. the state_dict tensors as they are) -> kernel layouts.  Every packed
+ * buffer has exactly w.numel() floats. */
+#define VQ2_PACK_FWD 0   /* operand of vq2_conv_fwd   */
+#define VQ2_PACK_DGRAD 1 /* operand of vq2_conv_dgrad */
+int vq2_pack_weight(const vq2_conv_desc *d, int which, const float *w, float *packed, vq2_stream_t stream);
+
+/* y = [relu]( conv_or_convT([relu]x, w) + bias [+ residual] )
+ * wp: VQ2_PACK_FWD packing of w.  bias may be NULL.  residual (same shape as y,
+ * pixel stride ldres) may be NULL: the `out += input` of vqvae.py:94. */
+int vq2_conv_fwd(const vq2_conv_desc *d, int flags, const float *x, const float *wp, const float *bias,
+                 const float *residual, int32_t ldres, float *y, vq2_stream_t stream);
+
+/* dx = dgrad(dy) [* (mask > 0)] [+ residual]
+ * wp: VQ2_PACK_DGRAD packing of w.  mask (shape of x, pixel stride ldmask): the
+ * pre-ReLU input when the forward op had VQ2_RELU_IN (ReLU backward fused);
+ * residual (shape of x): the skip-path gradient of a ResBlock.  dx has pixel
+ * stride lddx; dy has pixel stride d->ldy. */
+int vq2_conv_dgrad(const vq2_conv_desc *d, const float *dy, const float *wp, const float *mask, int32_t ldmask,
+                   const float *residual, int32_t ldres, float *dx, int32_t lddx, vq2_stream_t stream);
+
+/* dw (reference layout, OIHW or IOHW) = wgrad([relu]x, dy); deterministic
+ * split-K: partial slabs in `ws`, then an ordered reduction. flags: VQ2_RELU_IN. */
+size_t vq2_conv_wgrad_workspace_bytes(const vq2_conv_desc *d);
+int vq2_conv_wgrad(const vq2_conv_desc *d, int flags, const float *x, const float *dy, float *dw, void *ws,
+                   size_t ws_bytes, vq2_stream_t stream);
+
+/* db[c] = sum over pixels of dy[.,c]  (bias gradient).  ws: >= vq2_colsum_workspace_bytes. */
+size_t vq2_colsum_workspace_bytes(int64_t rows, int32_t C);
+int vq2_colsum(const float *dy, int64_t rows, int32_t C, int32_t ld, float *db, void *ws, size_t ws_bytes,
+               vq2_stream_t stream);
+
+/* ------------------------------------------------------------------ layout + elementwise */
+/* NCHW [N,C,H,W] -> NHWC with pixel stride ld (>= C); channels C..ld-1 are written as 0 */
+int vq2_nchw_to_nhwc(const float *src, float *dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t ld,
+                     vq2_stream_t stream);
+int vq2_nhwc_to_nchw(const float *src, float *dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t ld,
+                     vq2_stream_t stream);
+/* g = dy * (y > 0) over [pixels, C] with pixel strides: backward of a fused VQ2_RELU_OUT
+ * (vqvae.py:122,144); with dy == y it is the forward ReLU itself */
+int vq2_relu_bwd(const float *dy, int32_t lddy, const float *y, int32_t ldy, float *g, int32_t ldg, int64_t pixels,
+                 int32_t C, vq2_stream_t stream);
+/* dst[p*ldd + c] (+)= src[p*lds + c], c < C: channel-slice copy / accumulate */
+int vq2_slice_copy(const float *src, int32_t lds, float *dst, int32_t ldd, int64_t pixels, int32_t C,
+                   int accumulate, vq2_stream_t stream);
+
+/* ------------------------------------------------------------------ Quantize (vqvae.py:28-78)
+ * x[M,D] rows (NHWC latents), embed[D,K] (reference layout).
+ * vq2_vq_prepare: embedT[K,D] and enorm[K] = sum_d embed[d,k]^2      (vqvae.py:47)
+ * vq2_vq_fwd:  idx[M] (int64) = first argmin_k ||x||^2 - 2 x.e_k + ||e_k||^2 (vqvae.py:44-49)
+ *              out[M,D] = x + (e_idx - x)                            (vqvae.py:52,73)
+ *              loss_partial: per-workgroup sums of (e_idx - x)^2     (vqvae.py:72)
+ *              counts[K] += one-hot sum, sumsT[K,D] += scatter of x  (vqvae.py:55-56), if non-NULL
+ *              (counts/sumsT must be zeroed by the caller; float atomics)
+ * vq2_vq_loss: diff = sum(loss_partial) / (M*D)
+ * vq2_vq_bwd:  dx = g_out + (2/(M*D)) * g_diff * (x - e_idx)         (autograd of vqvae.py:72-73)
+ * vq2_vq_ema_update: in-place EMA of cluster_size/embed_avg/embed from (all-reduced) counts/sumsT
+ *                                                                   (vqvae.py:61-70)
+ * vq2_vq_gather: out[M,D] = embedT[idx]                              (vqvae.py:77-78 embed_code)
+ */
+int vq2_vq_prepare(const float *embed, float *embedT, float *enorm, int32_t D, int32_t K, vq2_stream_t stream);
+size_t vq2_vq_fwd_workspace_floats(int64_t M);
+int vq2_vq_fwd(const float *x, int32_t ldx, const float *embed, const float *embedT, const float *enorm, int64_t M,
+               int32_t D, int32_t K, int64_t *idx, float *out, int32_t ldo, float *loss_partial, float *counts,
+               float *sumsT, vq2_stream_t stream);
+int vq2_vq_loss(const float *loss_partial, int64_t M, int32_t D, float *diff, vq2_stream_t stream);
+int vq2_vq_bwd(const float *g_out, int32_t ldg, const float *g_diff, const float *x, int32_t ldx,
+               const int64_t *idx, const float *embedT, int64_t M, int32_t D, int32_t K, float *dx, int32_t lddx,
+               vq2_stream_t stream);
+int vq2_vq_ema_update(float *embed, float *cluster_size, float *embed_avg, const float *counts, const float *sumsT,
+                      int32_t D, int32_t K, double decay, double eps, vq2_stream_t stream);
+int vq2_vq_gather(const int64_t *idx, const float *embedT, int64_t M, int32_t D, int32_t K, float *out, int32_t ldo,
+                  vq2_stream_t stream);
+
+/* ------------------------------------------------------------------ loss + optimizer
+ * vq2_mse_fwd_bwd: loss = sum((a-b)^2)/denom (train_vqvae.py:31,83) over `numel` contiguous
+ *   elements (denom = numel, or the unpadded count when both operands carry zero padding);
+ *   grad (may be NULL) = (*gscale) * 2*(a-b)/denom  (gscale NULL = 1).  ws >= vq2_mse_workspace_bytes.
+ * vq2_adam_step: torch.optim.Adam (betas, eps, no weight decay; train_vqvae.py:185) over a
+ *   flat fp32 arena; `step` is the 1-based step count. */
+size_t vq2_mse_workspace_bytes(int64_t numel);
+int vq2_mse_fwd_bwd(const float *a, const float *b, int64_t numel, int64_t denom, const float *gscale, float *loss,
+                    float *grad, void *ws, size_t ws_bytes, vq2_stream_t stream);
+int vq2_adam_step(float *p, const float *g, float *m, float *v, int64_t n, double lr, double beta1, double beta2,
+                  double eps, int32_t step, double grad_scale, vq2_stream_t stream);
+/* dst = a + alpha * b (flat): the 0.25 * latent_loss accumulation and small host-free scalar math */
+int vq2_axpby(const float *a, const float *b, float alpha, float *dst, int64_t n, vq2_stream_t stream);
+/* dst = src * scalar[0] * alpha, scalar read on the device (upstream gradient of a loss) */
+int vq2_scale(const float *src, const float *scalar, float alpha, float *dst, int64_t n, vq2_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQ2_H */

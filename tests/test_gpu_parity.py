@@ -1,0 +1,342 @@
+"""GPU parity: libvq2 (through the C ABI, via vqvae2_amd) vs the reference's golden vectors and vs
+the CPU oracle on identical seeded inputs.  Indices must be bit-exact; floating point within the
+fp32 tolerances stated per test (different but valid fp32 accumulation orders)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import rng
+from oracle import vqvae_oracle as O
+from oracle.make_golden_cases import (BLOCK_CASES, CONV_FLAVOURS, SEED, block_state, conv_inputs,
+                                      quantize_inputs)
+
+pytestmark = pytest.mark.gpu
+
+RT, AT = 2e-4, 2e-5   # fp32 tolerance for activations/gradients (sums of up to ~2k products)
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def close(a, b, rtol=RT, atol=AT, what=""):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=what)
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import vqvae2_amd
+    return vqvae2_amd
+
+
+def test_native_library_is_loaded(amd):
+    import ctypes
+    assert isinstance(amd._lib.lib, ctypes.CDLL) and amd._lib.lib.vq2_version() >= 1
+    with open("/proc/self/maps") as f:
+        assert "libvq2.so" in f.read()
+
+
+def test_conv_flavours(amd, golden):
+    g = golden("convs")
+    for tag, kind, ws, stride, pad, hw in CONV_FLAVOURS:
+        x, w, b = conv_inputs(tag, kind, ws, hw)
+        if kind == "conv":
+            m = amd.Conv2d(ws[1], ws[0], ws[2], stride=stride, padding=pad)
+        else:
+            m = amd.ConvTranspose2d(ws[0], ws[1], ws[2], stride=stride, padding=pad)
+        m.load_state_dict({"weight": t(w), "bias": t(b)})
+        m.to(dev())
+        xt = t(x).to(dev()).requires_grad_(True)
+        y = m(xt)
+        assert tuple(y.shape) == tuple(g[f"{tag}.y"].shape), tag
+        close(y, g[f"{tag}.y"], what=f"{tag}.y")
+        y.backward(t(rng.normal(SEED, f"{tag}.gy", tuple(y.shape))).to(dev()))
+        close(xt.grad, g[f"{tag}.gx"], what=f"{tag}.gx")
+        close(m.weight.grad, g[f"{tag}.gw"], rtol=5e-4, atol=1e-4, what=f"{tag}.gw")
+        close(m.bias.grad, g[f"{tag}.gb"], rtol=5e-4, atol=1e-4, what=f"{tag}.gb")
+
+
+def _run_quantize(amd, tag, D, K, xshape, training, tie=False):
+    x, embed, cs0, gw = quantize_inputs(tag, D, K, xshape, tie)
+    q = amd.Quantize(D, K)
+    q.load_state_dict({"embed": t(embed), "cluster_size": t(cs0), "embed_avg": t(embed) * t(cs0)[None, :]})
+    q.to(dev()).train(training)
+    xt = t(x).to(dev()).requires_grad_(True)
+    out, diff, idx = q(xt)
+    ((out * t(gw).to(dev())).sum() + 0.25 * diff).backward()
+    return q, out, diff, idx, xt.grad
+
+
+def test_quantize_golden(amd, golden):
+    g = golden("quantize")
+    for tag, D, K, xs, tr, tie in [("q512_train", 64, 512, (2, 8, 8, 64), True, False),
+                                   ("q512_eval", 64, 512, (2, 8, 8, 64), False, False),
+                                   ("q512_tie", 64, 512, (2, 8, 8, 64), True, True),
+                                   ("q64_train", 16, 64, (2, 4, 4, 16), True, False)]:
+        q, out, diff, idx, gx = _run_quantize(amd, tag, D, K, xs, tr, tie)
+        assert idx.dtype == torch.int64 and tuple(idx.shape) == xs[:-1]
+        assert np.array_equal(idx.cpu().numpy().astype(np.int32), g[f"{tag}.idx"]), f"{tag}: indices differ"
+        close(out, g[f"{tag}.out"], rtol=1e-6, atol=1e-6, what=tag)
+        close(diff, g[f"{tag}.diff"], rtol=1e-5, atol=1e-7, what=tag)
+        close(gx, g[f"{tag}.xgrad"], rtol=1e-5, atol=1e-7, what=tag)
+        close(q.cluster_size, g[f"{tag}.cluster_size_after"], rtol=1e-5, atol=1e-6, what=tag)
+        close(q.embed_avg, g[f"{tag}.embed_avg_after"], rtol=1e-5, atol=1e-5, what=tag)
+        close(q.embed, g[f"{tag}.embed_after"], rtol=1e-4, atol=1e-5, what=tag)
+    gi = g["q512_tie.idx"].reshape(-1)
+    assert gi[0] == 5 and gi[1] == 64 and gi[2] == 5
+
+
+def test_quantize_8192_golden(amd, golden):
+    g = golden("quantize")
+    q, out, diff, idx, gx = _run_quantize(amd, "q8192_train", 64, 8192, (2, 16, 16, 64), True)
+    assert np.array_equal(idx.cpu().numpy().astype(np.int32), g["q8192_train.idx"])
+    close(out.reshape(-1, 64)[::16], g["q8192_train.out_rows"], rtol=1e-6, atol=1e-6)
+    close(q.cluster_size, g["q8192_train.cluster_size_after"], rtol=1e-5, atol=1e-6)
+
+
+def test_quantize_ragged_and_embed_code(amd):
+    # M not a multiple of the 128-row workgroup tile, several tiny shapes, eval mode
+    for M, D, K in [(1, 64, 512), (37, 64, 512), (129, 16, 64), (1000, 32, 128), (300, 8, 36), (5, 4, 4)]:
+        x = t(rng.normal(7, f"r.x{M}", (M, 1, 1, D)))
+        e = t(rng.normal(7, f"r.e{M}", (D, K)))
+        q = amd.Quantize(D, K)
+        q.load_state_dict({"embed": e, "cluster_size": torch.zeros(K), "embed_avg": e.clone()})
+        q.to(dev()).eval()
+        out, diff, idx = q(x.to(dev()))
+        ro, rd, ri = O.quantize_forward(x, e.clone(), torch.zeros(K), e.clone(), False)
+        margin, _ = O.quantize_margin(x, e)
+        bad = (idx.cpu() != ri).reshape(-1)
+        assert not bool((bad & (margin > 1e-4)).any()), (M, D, K)
+        if not bool(bad.any()):
+            close(out, ro, rtol=1e-6, atol=1e-6)
+            close(diff, rd, rtol=1e-5, atol=1e-7)
+        code = q.embed_code(idx)
+        close(code, F.embedding(idx.cpu(), e.t()), rtol=0, atol=0)
+
+
+def test_quantize_large_properties(amd):
+    # BASELINE config sizes (B=32 bottom level: M = 131072) through size-independent properties
+    D, K, M = 64, 512, 32 * 64 * 64
+    x = t(rng.normal(11, "big.x", (32, 64, 64, D))).to(dev())
+    e = t(rng.normal(11, "big.e", (D, K)))
+    q = amd.Quantize(D, K)
+    q.load_state_dict({"embed": e, "cluster_size": torch.zeros(K), "embed_avg": e.clone()})
+    q.to(dev()).train()
+    e0 = q.embed.clone()
+    out, diff, idx = q(x)
+    # (1) every index is the fp64 argmin wherever the fp64 margin is not a near-tie
+    margin, ref_idx = O.quantize_margin(x.cpu(), e)
+    bad = idx.cpu().reshape(-1) != ref_idx
+    assert int(bad.sum()) <= 8 and not bool((bad & (margin > 1e-3)).any())
+    # (2) cluster_size EMA: counts sum to M  ->  sum(cluster_size) = 0.01 * M
+    close(q.cluster_size.sum(), 0.01 * M, rtol=1e-5)
+    # (3) idempotence on the pre-update codebook: quantising the quantised output returns the same codes
+    q2 = amd.Quantize(D, K)
+    q2.load_state_dict({"embed": e0.cpu(), "cluster_size": torch.zeros(K), "embed_avg": e0.cpu()})
+    q2.to(dev()).eval()
+    code = q2.embed_code(idx)
+    _, d2, idx2 = q2(code)
+    assert torch.equal(idx2, idx) and float(d2) < 1e-12
+    # (4) diff equals the mean squared distance to the selected codes
+    close(diff, (code - x).pow(2).mean(), rtol=1e-4)
+
+
+def test_blocks(amd, golden):
+    g = golden("blocks")
+    for tag, kind, args, xs in BLOCK_CASES:
+        st = block_state(tag, kind, args)
+        if kind == "resblock":
+            m = amd.ResBlock(*args)
+        elif kind == "encoder":
+            m = amd.Encoder(*args[:4], stride=args[4])
+        else:
+            m = amd.Decoder(*args[:5], stride=args[5])
+        m.load_state_dict(st)
+        m.to(dev())
+        x = t(rng.normal(SEED, f"{tag}.x", xs)).to(dev()).requires_grad_(True)
+        y = m(x)
+        close(y, g[f"{tag}.y"], what=f"{tag}.y")
+        y.backward(t(rng.normal(SEED, f"{tag}.gy", tuple(y.shape))).to(dev()))
+        close(x.grad, g[f"{tag}.gx"], what=f"{tag}.gx")
+        for k, p in m.named_parameters():
+            close(p.grad, g[f"{tag}.g.{k}"], rtol=5e-4, atol=1e-4, what=f"{tag}.g.{k}")
+
+
+def _tiny(amd):
+    cfg = O.TINY
+    m = amd.VQVAE(channel=cfg.channel, n_res_block=cfg.n_res_block, n_res_channel=cfg.n_res_channel,
+                  embed_dim=cfg.embed_dim, n_embed=cfg.n_embed)
+    m.load_state_dict(O.make_state(cfg, SEED))
+    return m.to(dev())
+
+
+def test_tiny_vqvae_dropin_api_three_adam_steps(amd, golden):
+    """The reference's own loop (train_vqvae.py:83-91) with stock nn.MSELoss + torch.optim.Adam."""
+    g = golden("tiny_vqvae")
+    m = _tiny(amd)
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=3e-4)
+    crit = torch.nn.MSELoss()
+    for step in range(3):
+        img = O.make_images(2, 32, SEED + 100 * step).to(dev())
+        opt.zero_grad()
+        dec, diff = m(img)
+        assert tuple(dec.shape) == (2, 3, 32, 32) and tuple(diff.shape) == (1,)
+        recon = crit(dec, img)
+        latent = diff.mean()
+        loss = recon + 0.25 * latent
+        loss.backward()
+        if step == 0:
+            close(dec, g["s0.dec"], what="dec")
+            close(diff, g["s0.diff"], rtol=1e-5, atol=1e-7)
+            for k, p in m.named_parameters():
+                if k.startswith("dec_ir."):
+                    assert p.grad is None
+                else:
+                    close(p.grad, g[f"s0.g.{k}"], rtol=1e-3, atol=2e-6, what=k)
+        close(loss, g[f"s{step}.loss"], rtol=1e-4)
+        opt.step()
+        if step in (0, 2):
+            for k, v in m.state_dict().items():
+                if not k.startswith("dec_ir."):
+                    close(v, g[f"s{step}.after.{k}"], rtol=1e-3, atol=1e-4 if step else 2e-5, what=k)
+
+
+def test_tiny_vqvae_encode_decode(amd, golden):
+    g = golden("tiny_vqvae")
+    m = _tiny(amd).eval()
+    img = O.make_images(2, 32, SEED).to(dev())
+    with torch.no_grad():
+        qt, qb, diff, id_t, id_b = m.encode(img)
+        assert np.array_equal(id_t.cpu().numpy().astype(np.int32), g["s0.id_t"])
+        assert np.array_equal(id_b.cpu().numpy().astype(np.int32), g["s0.id_b"])
+        close(qt, g["s0.quant_t"], rtol=1e-5, atol=1e-5)
+        close(qb, g["s0.quant_b"], rtol=1e-5, atol=1e-5)
+        close(diff, g["eval.diff"], rtol=1e-5)
+        dec, _ = m(img)
+        dec2 = m.decode_code(id_t, id_b)          # upstream semantics of vqvae.py:251-259
+        st = O.make_state(O.TINY, SEED)
+        ref = O.vqvae_decode_code(st, O.TINY, id_t.cpu(), id_b.cpu())
+        close(dec2, ref)
+        close(dec2, dec, rtol=1e-4, atol=1e-5)      # STE value x+(q-x) vs q differ by one rounding
+        assert m.embed_dim == 2 * O.TINY.embed_dim
+
+
+def test_trainer_matches_oracle_three_steps(amd, golden):
+    g = golden("tiny_vqvae")
+    m = _tiny(amd)
+    tr = amd.Stage1Trainer(m, lr=3e-4)
+    for step in range(3):
+        out = tr.step(O.make_images(2, 32, SEED + 100 * step).to(dev()))
+        close(out["loss"], g[f"s{step}.loss"], rtol=1e-4)
+        close(out["recon"], g[f"s{step}.recon"], rtol=1e-4)
+        close(out["latent"], g[f"s{step}.latent"], rtol=1e-4)
+        assert tr.arena.grads_ready(), "gradients must land in the flat arena (one-launch Adam)"
+        if step in (0, 2):
+            for k, v in m.state_dict().items():
+                if not k.startswith("dec_ir."):
+                    close(v, g[f"s{step}.after.{k}"], rtol=1e-3, atol=1e-4 if step else 2e-5, what=k)
+
+
+def test_single_level_config1(amd, golden):
+    """BASELINE config 1: Encoder(s=4) -> 1x1 -> Quantize -> Decoder(s=4), 32x32, batch 16."""
+    g = golden("single_level")
+    cfg = O.DEFAULT
+    st = O.make_single_level_state(cfg, SEED)
+    enc = amd.Encoder(3, 128, 2, 32, stride=4)
+    qconv = amd.Conv2d(128, 64, 1)
+    quant = amd.Quantize(64, 512)
+    dec = amd.Decoder(64, 3, 128, 2, 32, stride=4)
+    enc.load_state_dict({k[4:]: v for k, v in st.items() if k.startswith("enc.")})
+    qconv.load_state_dict({k[len("quantize_conv."):]: v for k, v in st.items() if k.startswith("quantize_conv.")})
+    quant.load_state_dict({k[len("quantize."):]: v for k, v in st.items() if k.startswith("quantize.")})
+    dec.load_state_dict({k[4:]: v for k, v in st.items() if k.startswith("dec.")})
+    for mod in (enc, qconv, quant, dec):
+        mod.to(dev())
+    img = O.make_images(16, 32, SEED).to(dev())
+    h = qconv(enc(img)).permute(0, 2, 3, 1)
+    q, diff, idx = quant(h)
+    out = dec(q.permute(0, 3, 1, 2))
+    recon = F.mse_loss(out, img)
+    loss = recon + 0.25 * diff
+    loss.backward()
+    assert np.array_equal(idx.cpu().numpy().astype(np.int32), g["idx"])
+    close(out[:2], g["dec"])
+    close(loss, g["loss"], rtol=1e-4)
+    for name, mod in (("enc", enc), ("quantize_conv", qconv), ("dec", dec)):
+        for k, p in mod.named_parameters():
+            close(p.grad.norm(), g[f"gnorm.{name}.{k}"], rtol=1e-3)
+    close(quant.cluster_size, g["cluster_size_after"], rtol=1e-5, atol=1e-6)
+
+
+def test_full256_default_model(amd, golden):
+    """BASELINE config 2 geometry (256x256, default VQVAE) at batch 2 against the reference's outputs."""
+    g = golden("full256")
+    cfg = O.DEFAULT
+    st = O.make_state(cfg, SEED)
+    m = amd.VQVAE()
+    m.load_state_dict(st)
+    m.to(dev()).train()
+    img = O.make_images(2, 256, SEED).to(dev())
+    ids = {}
+    m.quantize_t.register_forward_hook(lambda mod, i, o: ids.__setitem__("t", o[2]))
+    m.quantize_b.register_forward_hook(lambda mod, i, o: ids.__setitem__("b", o[2]))
+    tr = amd.Stage1Trainer(m, lr=3e-4)
+    out = tr.step(img)
+    nt = int((ids["t"].cpu().numpy().astype(np.int16) != g["id_t"]).sum())
+    nb = int((ids["b"].cpu().numpy().astype(np.int16) != g["id_b"]).sum())
+    assert nt == 0 and nb == 0, f"index mismatches top={nt} bottom={nb}"
+    close(out["recon"], g["recon"], rtol=1e-4)
+    close(out["loss"], g["loss"], rtol=1e-4)
+    close(out["dec"][:, :, ::16, ::16], g["dec_sample"], rtol=1e-3, atol=1e-4)
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            close(p.grad.norm(), g[f"gnorm.{k}"], rtol=2e-3, what=k)
+    close(m.quantize_t.cluster_size, g["cluster_size_t_after"], rtol=1e-5, atol=1e-6)
+    close(m.quantize_b.cluster_size, g["cluster_size_b_after"], rtol=1e-5, atol=1e-6)
+
+
+def test_baseline_batch32_properties(amd):
+    """BASELINE configs[1] at its full size (256x256, batch 32): size-independent properties."""
+    cfg = O.DEFAULT
+    m = amd.VQVAE()
+    m.load_state_dict(O.make_state(cfg, SEED))
+    m.to(dev())
+    img = O.make_images(32, 256, SEED).to(dev())
+    tr = amd.Stage1Trainer(m, lr=3e-4)
+    out = tr.step(img)
+    assert torch.isfinite(out["loss"]).item()
+    # EMA counts: one vote per latent vector (top 32*32*32, bottom 32*64*64)
+    close(m.quantize_t.cluster_size.sum(), 0.01 * 32 * 32 * 32, rtol=1e-5)
+    close(m.quantize_b.cluster_size.sum(), 0.01 * 32 * 64 * 64, rtol=1e-5)
+    # batch linearity: the first 2 images reproduce the batch-2 reconstruction (no cross-image coupling)
+    m2 = amd.VQVAE()
+    m2.load_state_dict(O.make_state(cfg, SEED))
+    m2.to(dev()).eval()
+    with torch.no_grad():
+        d32, _ = m2(img)
+        d2, _ = m2(img[:2].contiguous())
+        close(d32[:2], d2, rtol=0, atol=0)
+        # encode -> decode_code round trip equals forward
+        _, _, _, id_t, id_b = m2.encode(img[:4].contiguous())
+        close(m2.decode_code(id_t, id_b), d32[:4], rtol=1e-4, atol=1e-5)
+
+
+def test_error_behaviour(amd):
+    with pytest.raises(RuntimeError):
+        amd.Conv2d(8, 8, 3, padding=1).to(dev())(torch.zeros(1, 8, 4, 4))         # CPU tensor: no fallback
+    with pytest.raises(NotImplementedError):
+        amd.Conv2d(8, 8, 3, stride=3)
+    with pytest.raises(RuntimeError):
+        amd.Quantize(16, 64).to(dev())(torch.zeros(1, 2, 2, 8, device=dev()))
+    d = amd._lib.ConvDesc()
+    assert amd._lib.lib.vq2_conv_fwd(d, 0, None, None, None, None, 0, None, None) != 0
+    assert b"conv" in amd._lib.lib.vq2_last_error()

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Build libvq2.so (gfx950 only) in-tree next to the Python package.
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+OUT="$HERE/../libvq2.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function"
+mkdir -p "$HERE/_obj"
+pids=()
+for f in vq2_conv vq2_wgrad vq2_vq vq2_elem; do
+  if [ ! -f "$HERE/_obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/_obj/$f.o" ] || [ "$HERE/vq2_common.h" -nt "$HERE/_obj/$f.o" ] || [ "$HERE/../../include/vq2.h" -nt "$HERE/_obj/$f.o" ]; then
+    $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$HERE/_obj/$f.o" ${VQ2_EXTRA_FLAGS:-} &
+    pids+=($!)
+  fi
+done
+$HIPCC $FLAGS -x hip -c "$HERE/vq2_core.cpp" -o "$HERE/_obj/vq2_core.o" &
+pids+=($!)
+for p in "${pids[@]}"; do wait "$p"; done
+$HIPCC -shared -fPIC --offload-arch=gfx950 "$HERE"/_obj/*.o -o "$OUT"
+echo "built $OUT"

@@ -1,0 +1,45 @@
+// Shared device/host helpers for libvq2 (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/vq2.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace vq2 {
+
+// thread-local error message (forward runs on the main thread, backward on an autograd thread)
+int set_error(int code, const char *fmt, ...);
+int check_launch(const char *what);
+
+static inline hipStream_t to_stream(vq2_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+__device__ __forceinline__ float4 relu4(float4 v) {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Allow > 64 KiB of dynamic LDS for a kernel (gfx950 has 160 KiB per CU).
+template <typename K>
+static inline void allow_big_lds(K kernel, size_t bytes) {
+    if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+}  // namespace vq2
+
+#define VQ2_REQUIRE(cond, ...)                                           \
+    do {                                                                 \
+        if (!(cond)) return vq2::set_error(VQ2_ERR_INVALID, __VA_ARGS__); \
+    } while (0)

@@ -1,0 +1,375 @@
+// NHWC conv2d / conv-transpose2d forward and data-gradient for gfx950 (MI355X).
+//
+// One kernel family: an implicit GEMM whose A operand is gathered on the fly from the
+// NHWC activation (im2col never materialised), B operand is a packed weight panel, and
+// whose inner product is the exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32
+// (bit-identical to an fmaf chain, 64 FLOP/clk/SIMD = the fp32 peak of the chip).
+//
+//   GEMM rows  m = (n, ho, wo) of a "virtual" output grid
+//   GEMM cols  co
+//   GEMM depth k = (kh, kw, ci), ci fastest  -> 16-byte coalesced loads along ci
+//
+// Everything the reference does around a conv on this path is fused:
+//   - ReLU on the input (vqvae.py:86,88,107,109,...)      -> applied while staging A into LDS
+//   - bias                                                 -> epilogue
+//   - `out += input` of ResBlock (vqvae.py:94)             -> residual in the epilogue
+//   - trailing in-place ReLU (vqvae.py:122,144)            -> epilogue
+//   - ReLU backward (mask by pre-activation)               -> epilogue of the dgrad launch
+//   - torch.cat (vqvae.py:218,233)                         -> pixel strides ldx/ldy on channel slices
+//
+// ConvTranspose2d(k4,s2,p1) and the data-gradient of a stride-2 4x4 conv are the same
+// sub-pixel decomposition: 4 output phases, each a 2x2 stride-1 conv; blockIdx.z = phase.
+#include "vq2_common.h"
+
+namespace vq2 {
+
+struct ConvGemmParams {
+    const float *x;   // [N,H,W,ldx]
+    const float *w;   // [phases][Co][K]   (K = KH*KW*Ci, ci fastest)
+    const float *bias;  // [Co] or null
+    const float *mask;  // shape of y (pixel stride ldm) or null: y *= (mask > 0)
+    const float *res;   // shape of y (pixel stride ldr) or null: y += res
+    float *y;           // [N,Hy,Wy,ldy]
+    int N, H, W, Ci, ldx;
+    int Ho, Wo, Co, ldy;  // virtual output grid (rows of the GEMM) and channels
+    int KH, KW, stride, pad_h, pad_w;
+    int K, M;             // K = KH*KW*Ci, M = N*Ho*Wo
+    int phases;           // 1, or 4 for the sub-pixel transposed conv
+    int Hy, Wy;           // real output image size
+    int ldm, ldr;
+    int relu_in, relu_out;
+    int nbias;            // bias has nbias entries (real output channels)
+};
+
+constexpr int BK = 32;        // depth of one staged chunk
+constexpr int LDK = BK + 4;   // padded LDS row: 144 B -> ds_read_b128 conflict-free
+
+template <int WAVES_M, int WAVES_N, int MT, int NT>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams P) {
+    constexpr int BM = WAVES_M * MT * 32;
+    constexpr int BN = WAVES_N * NT * 32;
+    constexpr int A_LD = BM / 32;  // float4 loads per thread per chunk (A)
+    constexpr int B_LD = BN / 32;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                  // [2][BM][LDK]
+    float *Bs = smem + 2 * BM * LDK;   // [2][BN][LDK]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WAVES_N;
+    const int wn = wave % WAVES_N;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    int pad_h = P.pad_h, pad_w = P.pad_w, oh = 0, ow = 0, os = 1;
+    const float *wp = P.w;
+    if (P.phases == 4) {
+        const int ph = blockIdx.z >> 1, pw = blockIdx.z & 1;
+        pad_h = 1 - ph; pad_w = 1 - pw; oh = ph; ow = pw; os = 2;
+        wp += (size_t)blockIdx.z * P.Co * P.K;
+    }
+
+    // ---- per-thread staging coordinates (fixed over the K loop)
+    const int lrow = tid >> 3;        // 0..31
+    const int lk = (tid & 7) * 4;     // float4 column inside a chunk
+    int a_pix[A_LD], a_h[A_LD], a_w[A_LD];
+    const int HoWo = P.Ho * P.Wo;
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+        const int m = m0 + lrow + 32 * j;
+        if (m < P.M) {
+            const int n = m / HoWo;
+            const int r = m - n * HoWo;
+            const int ho = r / P.Wo;
+            const int wo = r - ho * P.Wo;
+            a_h[j] = ho * P.stride - pad_h;
+            a_w[j] = wo * P.stride - pad_w;
+            a_pix[j] = (n * P.H + a_h[j]) * P.W + a_w[j];
+        } else {
+            a_h[j] = -(1 << 24); a_w[j] = 0; a_pix[j] = 0;  // every bounds test fails
+        }
+    }
+    // k -> (kh, kw, ci) of this thread's float4, advanced incrementally
+    int kglob = lk;
+    int ci, kh, kw;
+    {
+        const int tap = kglob / P.Ci;
+        ci = kglob - tap * P.Ci;
+        kh = tap / P.KW;
+        kw = tap - kh * P.KW;
+    }
+
+    float4 ra[A_LD], rb[B_LD];
+    auto load_chunk = [&]() {
+        const bool kv = kglob < P.K;
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            const bool v = kv && (unsigned)(a_h[j] + kh) < (unsigned)P.H && (unsigned)(a_w[j] + kw) < (unsigned)P.W;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (v) val = *reinterpret_cast<const float4 *>(P.x + (size_t)(a_pix[j] + kh * P.W + kw) * P.ldx + ci);
+            ra[j] = P.relu_in ? relu4(val) : val;
+        }
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) {
+            const int co = n0 + lrow + 32 * j;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kv && co < P.Co) val = *reinterpret_cast<const float4 *>(wp + (size_t)co * P.K + kglob);
+            rb[j] = val;
+        }
+    };
+    auto advance_k = [&]() {
+        kglob += BK;
+        ci += BK;
+        while (ci >= P.Ci) {
+            ci -= P.Ci;
+            if (++kw == P.KW) { kw = 0; ++kh; }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        float *a = As + buf * BM * LDK;
+        float *b = Bs + buf * BN * LDK;
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) *reinterpret_cast<float4 *>(a + (lrow + 32 * j) * LDK + lk) = ra[j];
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) *reinterpret_cast<float4 *>(b + (lrow + 32 * j) * LDK + lk) = rb[j];
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nchunks = (P.K + BK - 1) / BK;
+    load_chunk();
+    store_chunk(0);
+    __syncthreads();
+
+    const int frag_row = lane & 31;
+    const int frag_k = 4 * (lane >> 5);
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) {
+            advance_k();
+            load_chunk();  // global loads in flight while the matrix pipe works on chunk c
+        }
+        const float *a = As + buf * BM * LDK + (wm * MT * 32 + frag_row) * LDK + frag_k;
+        const float *b = Bs + buf * BN * LDK + (wn * NT * 32 + frag_row) * LDK + frag_k;
+#pragma unroll
+        for (int k8 = 0; k8 < BK / 8; ++k8) {
+            float4 fa[MT], fb[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const float4 *>(a + i * 32 * LDK + k8 * 8);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const float4 *>(b + j * 32 * LDK + k8 * 8);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (c + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds column (lane&31) of 16 rows per 32x32 tile
+    const int colq = lane & 31;
+    const int rowq = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int co = n0 + (wn * NT + j) * 32 + colq;
+        const bool cv = co < P.Co;
+        const float bv = (P.bias && co < P.nbias) ? P.bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int mb = m0 + (wm * MT + i) * 32 + rowq;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                if (!cv || m >= P.M) continue;
+                size_t pix;
+                if (os == 1) {
+                    pix = (size_t)m;
+                } else {
+                    const int n = m / HoWo;
+                    const int rr = m - n * HoWo;
+                    const int ho = rr / P.Wo;
+                    const int wo = rr - ho * P.Wo;
+                    pix = ((size_t)n * P.Hy + (ho * os + oh)) * P.Wy + (wo * os + ow);
+                }
+                float v = acc[i][j][r] + bv;
+                if (P.mask) v = (P.mask[pix * P.ldm + co] > 0.f) ? v : 0.f;
+                if (P.res) v += P.res[pix * P.ldr + co];
+                if (P.relu_out) v = fmaxf(v, 0.f);
+                P.y[pix * P.ldy + co] = v;
+            }
+        }
+    }
+}
+
+template <int WAVES_M, int WAVES_N, int MT, int NT>
+static int launch_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
+    constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
+    const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+    auto kern = conv_gemm_kernel<WAVES_M, WAVES_N, MT, NT>;
+    allow_big_lds(kern, lds);
+    dim3 grid((P.M + BM - 1) / BM, (P.Co + BN - 1) / BN, P.phases);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, P);
+    return check_launch("conv_gemm_kernel");
+}
+
+static int run_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
+    // tile choice by output-channel count (GEMM N): keep the matrix pipe fed with full tiles
+    if (P.Co > 64) return launch_conv_gemm<2, 2, 2, 2>(P, s);   // 128 x 128
+    if (P.Co > 32) return launch_conv_gemm<2, 2, 2, 1>(P, s);   // 128 x 64
+    return launch_conv_gemm<4, 1, 2, 1>(P, s);                  // 256 x 32
+}
+
+// ------------------------------------------------------------------ weight packing
+// w is the reference tensor [Or][Ir][KH][KW] (real channel counts); the packed panel uses the
+// padded counts Op >= Or, Ip >= Ir and zero-fills.
+// mode 0: -> p[Op][kh*KW+kw][Ip]
+// mode 1: -> p[Ip][(KH-1-kh)*KW+(KW-1-kw)][Op]                    (stride-1 data gradient)
+// mode 2: w[A][B][4][4] -> p[ph*2+pw][Bp][a*2+b][Ap],  kh = 3-2a-ph, kw = 3-2b-pw   (sub-pixel; A=dim0, B=dim1)
+__global__ void pack_weight_kernel(const float *__restrict__ w, float *__restrict__ p, int Or, int Ir, int Op, int Ip,
+                                   int KH, int KW, int mode) {
+    const int taps = KH * KW;
+    const int total = Op * Ip * taps;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        int o, i, kh, kw;
+        if (mode == 0) {
+            i = t % Ip; const int tap = (t / Ip) % taps; o = t / (Ip * taps);
+            kh = tap / KW; kw = tap % KW;
+        } else if (mode == 1) {
+            o = t % Op; const int tapf = (t / Op) % taps; i = t / (Op * taps);
+            kh = KH - 1 - tapf / KW; kw = KW - 1 - tapf % KW;
+        } else {
+            o = t % Op; const int ab = (t / Op) % 4; i = (t / (Op * 4)) % Ip; const int phase = t / (Op * 4 * Ip);
+            kh = 3 - 2 * (ab >> 1) - (phase >> 1); kw = 3 - 2 * (ab & 1) - (phase & 1);
+        }
+        p[t] = (o < Or && i < Ir) ? w[((o * Ir + i) * KH + kh) * KW + kw] : 0.f;
+    }
+}
+
+static int check_desc(const vq2_conv_desc *d) {
+    VQ2_REQUIRE(d != nullptr, "conv desc is null");
+    VQ2_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Ci > 0 && d->Co > 0, "conv desc: non-positive dims");
+    VQ2_REQUIRE(d->Ci % 4 == 0 && d->Co % 4 == 0, "conv desc: Ci=%d, Co=%d must be multiples of 4", d->Ci, d->Co);
+    VQ2_REQUIRE(d->ldx >= d->Ci && d->ldx % 4 == 0, "conv desc: ldx=%d must be >= Ci and a multiple of 4", d->ldx);
+    VQ2_REQUIRE(d->ldy >= d->Co && d->ldy % 4 == 0, "conv desc: ldy=%d must be >= Co and a multiple of 4", d->ldy);
+    VQ2_REQUIRE(d->Cir >= 0 && d->Cir <= d->Ci && d->Cor >= 0 && d->Cor <= d->Co, "conv desc: Cir/Cor out of range");
+    if (d->transposed) {
+        VQ2_REQUIRE(d->KH == 4 && d->KW == 4 && d->stride == 2 && d->pad == 1,
+                    "conv-transpose supports k4 s2 p1 only (vqvae.py:150-160,191-193)");
+    } else {
+        VQ2_REQUIRE(d->KH >= 1 && d->KH <= 7 && d->KW == d->KH, "conv: square kernel 1..7 required");
+        VQ2_REQUIRE(d->stride == 1 || d->stride == 2, "conv: stride 1 or 2");
+        VQ2_REQUIRE(d->pad >= 0 && d->pad < d->KH, "conv: 0 <= pad < KH");
+        VQ2_REQUIRE(d->H + 2 * d->pad >= d->KH && d->W + 2 * d->pad >= d->KW, "conv: kernel larger than padded input");
+        if (d->stride == 2) VQ2_REQUIRE(d->KH == 4 && d->pad == 1 && d->H % 2 == 0 && d->W % 2 == 0,
+                                        "stride-2 conv supports k4 p1 on even sizes (vqvae.py:105,107,114)");
+    }
+    int Ho, Wo;
+    if (d->transposed) { Ho = 2 * d->H; Wo = 2 * d->W; }
+    else { Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1; Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1; }
+    const int64_t lim = (int64_t)1 << 31;
+    VQ2_REQUIRE((int64_t)d->N * d->H * d->W * d->ldx < lim && (int64_t)d->N * Ho * Wo * d->ldy < lim,
+                "conv: tensor exceeds 2^31 elements (int32 indexing)");
+    return VQ2_OK;
+}
+
+static void out_dims(const vq2_conv_desc *d, int &Ho, int &Wo) {
+    if (d->transposed) { Ho = 2 * d->H; Wo = 2 * d->W; }
+    else { Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1; Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1; }
+}
+
+}  // namespace vq2
+
+using namespace vq2;
+
+extern "C" int vq2_pack_weight(const vq2_conv_desc *d, int which, const float *w, float *packed, vq2_stream_t stream) {
+    if (int e = check_desc(d)) return e;
+    VQ2_REQUIRE(w && packed, "pack_weight: null pointer");
+    VQ2_REQUIRE(which == VQ2_PACK_FWD || which == VQ2_PACK_DGRAD, "pack_weight: bad `which`");
+    const int cir = d->Cir ? d->Cir : d->Ci, cor = d->Cor ? d->Cor : d->Co;
+    int mode, Or, Ir, Op, Ip;
+    if (!d->transposed) {
+        Or = cor; Ir = cir; Op = d->Co; Ip = d->Ci;   // w is [Co][Ci][KH][KW]
+        if (which == VQ2_PACK_FWD) mode = 0;
+        else mode = (d->stride == 1) ? 1 : 2;          // stride-2 dgrad = sub-pixel with A = Co (dim0), B = Ci (dim1)
+    } else {
+        Or = cir; Ir = cor; Op = d->Ci; Ip = d->Co;   // w is [Ci][Co][4][4]
+        mode = (which == VQ2_PACK_FWD) ? 2 : 0;        // dgrad: strided conv with O = Ci, I = Co
+    }
+    const int total = Op * Ip * d->KH * d->KW;
+    const int blocks = (total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, to_stream(stream), w, packed, Or, Ir, Op, Ip,
+                       d->KH, d->KW, mode);
+    return check_launch("pack_weight_kernel");
+}
+
+extern "C" int vq2_conv_fwd(const vq2_conv_desc *d, int flags, const float *x, const float *wp, const float *bias,
+                            const float *residual, int32_t ldres, float *y, vq2_stream_t stream) {
+    if (int e = check_desc(d)) return e;
+    VQ2_REQUIRE(x && wp && y, "conv_fwd: null pointer");
+    VQ2_REQUIRE(aligned16(x) && aligned16(wp) && aligned16(y), "conv_fwd: pointers must be 16-byte aligned");
+    VQ2_REQUIRE(!residual || (ldres >= d->Co), "conv_fwd: ldres < Co");
+    ConvGemmParams P{};
+    P.x = x; P.w = wp; P.bias = bias; P.mask = nullptr; P.res = residual; P.y = y;
+    P.N = d->N; P.H = d->H; P.W = d->W; P.Ci = d->Ci; P.ldx = d->ldx;
+    P.Co = d->Co; P.ldy = d->ldy; P.ldr = ldres; P.ldm = 0;
+    P.relu_in = (flags & VQ2_RELU_IN) != 0; P.relu_out = (flags & VQ2_RELU_OUT) != 0;
+    P.nbias = d->Cor ? d->Cor : d->Co;
+    out_dims(d, P.Hy, P.Wy);
+    if (!d->transposed) {
+        P.KH = d->KH; P.KW = d->KW; P.stride = d->stride; P.pad_h = P.pad_w = d->pad;
+        P.Ho = P.Hy; P.Wo = P.Wy; P.phases = 1;
+    } else {
+        P.KH = 2; P.KW = 2; P.stride = 1; P.pad_h = P.pad_w = 1;
+        P.Ho = d->H; P.Wo = d->W; P.phases = 4;
+    }
+    P.K = P.KH * P.KW * P.Ci; P.M = P.N * P.Ho * P.Wo;
+    return run_conv_gemm(P, to_stream(stream));
+}
+
+extern "C" int vq2_conv_dgrad(const vq2_conv_desc *d, const float *dy, const float *wp, const float *mask,
+                              int32_t ldmask, const float *residual, int32_t ldres, float *dx, int32_t lddx,
+                              vq2_stream_t stream) {
+    if (int e = check_desc(d)) return e;
+    VQ2_REQUIRE(dy && wp && dx, "conv_dgrad: null pointer");
+    VQ2_REQUIRE(aligned16(dy) && aligned16(wp) && aligned16(dx), "conv_dgrad: pointers must be 16-byte aligned");
+    VQ2_REQUIRE(lddx >= d->Ci && lddx % 4 == 0, "conv_dgrad: lddx=%d must be >= Ci and a multiple of 4", lddx);
+    VQ2_REQUIRE((!mask || ldmask >= d->Ci) && (!residual || ldres >= d->Ci), "conv_dgrad: ldmask/ldres < Ci");
+    int Hy, Wy;
+    out_dims(d, Hy, Wy);
+    ConvGemmParams P{};
+    // the gradient GEMM reads dy [N,Hy,Wy,Co] and produces dx [N,H,W,Ci]
+    P.x = dy; P.w = wp; P.bias = nullptr; P.mask = mask; P.res = residual; P.y = dx;
+    P.N = d->N; P.H = Hy; P.W = Wy; P.Ci = d->Co; P.ldx = d->ldy;
+    P.Co = d->Ci; P.ldy = lddx; P.ldm = ldmask; P.ldr = ldres;
+    P.relu_in = 0; P.relu_out = 0;
+    P.Hy = d->H; P.Wy = d->W;
+    if (!d->transposed && d->stride == 1) {
+        // full correlation with the flipped kernel: pad' = KH-1-pad
+        P.KH = d->KH; P.KW = d->KW; P.stride = 1; P.pad_h = P.pad_w = d->KH - 1 - d->pad;
+        P.Ho = d->H; P.Wo = d->W; P.phases = 1;
+    } else if (!d->transposed) {
+        // stride-2 k4 p1: dx = conv_transpose(dy): sub-pixel phases over the dy grid
+        P.KH = 2; P.KW = 2; P.stride = 1; P.pad_h = P.pad_w = 1;
+        P.Ho = Hy; P.Wo = Wy; P.phases = 4;
+    } else {
+        // conv-transpose: dx = strided conv of dy (k4 s2 p1)
+        P.KH = 4; P.KW = 4; P.stride = 2; P.pad_h = P.pad_w = 1;
+        P.Ho = d->H; P.Wo = d->W; P.phases = 1;
+    }
+    P.K = P.KH * P.KW * P.Ci; P.M = P.N * P.Ho * P.Wo;
+    return run_conv_gemm(P, to_stream(stream));
+}

@@ -1,0 +1,313 @@
+// Quantize (vqvae.py:28-78) for gfx950: fused distance GEMM + argmin + gather + STE output +
+// commitment-loss partials + EMA statistics, never materialising the [M,K] distance matrix.
+//
+// Distance GEMM orientation: codes are the MFMA *rows* (A operand, streamed through LDS),
+// latent vectors are the *columns* (B operand, held in registers for the whole kernel):
+//     S[code][vec] = sum_d E[d][code] * x[vec][d]        (v_mfma_f32_32x32x2_f32, exact fp32)
+// so each lane owns ONE latent vector (column = lane&31) and sees 16 codes per tile in its
+// accumulator registers: the running (min, argmin) over all K codes is lane-local, and the
+// only cross-lane step is one exchange between the two half-waves (lane ^ 32) at the end.
+// Ties: codes are visited in increasing order with a strict '<', and the half-wave exchange
+// prefers the smaller index -> first minimal index, like (-dist).max(1) at vqvae.py:49.
+//
+// dist is evaluated exactly as the reference writes it (vqvae.py:44-48):
+//     (||x||^2 - 2*(x.e)) + ||e||^2      in fp32, in that order.
+#include "vq2_common.h"
+
+namespace vq2 {
+
+constexpr int VQ_CT = 128;      // codes staged per LDS tile
+constexpr int VQ_ROWS = 128;    // latent vectors per workgroup (32 per wave)
+
+template <int DP>  // DP = D rounded up to {16,32,64}
+__global__ __launch_bounds__(256) void vq_fwd_kernel(const float *__restrict__ x, int ldx,
+                                                     const float *__restrict__ embed,   // [D][K]
+                                                     const float *__restrict__ embedT,  // [K][D]
+                                                     const float *__restrict__ enorm,   // [K]
+                                                     int64_t M, int D, int K, int64_t *__restrict__ idx_out,
+                                                     float *__restrict__ out, int ldo,
+                                                     float *__restrict__ loss_partial, float *__restrict__ counts,
+                                                     float *__restrict__ sumsT) {
+    constexpr int HS = DP / 2;  // MFMA k-steps; lane half h covers d in [h*HS, (h+1)*HS)
+    __shared__ __attribute__((aligned(16))) float Es[DP * VQ_CT];
+    __shared__ float En[VQ_CT];
+    __shared__ float wsum[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const int64_t row = (int64_t)blockIdx.x * VQ_ROWS + wave * 32 + col;
+    const bool rv = row < M;
+
+    // this lane's half of its latent vector, as MFMA B fragments
+    float xf[HS];
+#pragma unroll
+    for (int s = 0; s < HS; s += 4) {
+        const int d = h * HS + s;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rv && d < D) v = *reinterpret_cast<const float4 *>(x + row * ldx + d);
+        xf[s] = v.x; xf[s + 1] = v.y; xf[s + 2] = v.z; xf[s + 3] = v.w;
+    }
+    float xx = 0.f;
+#pragma unroll
+    for (int s = 0; s < HS; ++s) xx += xf[s] * xf[s];
+    xx += __shfl_xor(xx, 32, 64);
+
+    float best = __builtin_inff();
+    int besti = 0;
+
+    for (int ct0 = 0; ct0 < K; ct0 += VQ_CT) {
+        __syncthreads();
+        // stage E[:, ct0:ct0+128] (zero-padded) and its norms
+        for (int t = tid; t < DP * (VQ_CT / 4); t += 256) {
+            const int d = t / (VQ_CT / 4), c4 = (t % (VQ_CT / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (d < D && ct0 + c4 < K) v = *reinterpret_cast<const float4 *>(embed + (size_t)d * K + ct0 + c4);
+            *reinterpret_cast<float4 *>(Es + d * VQ_CT + c4) = v;
+        }
+        if (tid < VQ_CT) En[tid] = (ct0 + tid < K) ? enorm[ct0 + tid] : 0.f;
+        __syncthreads();
+
+#pragma unroll 1
+        for (int sub = 0; sub < VQ_CT / 32; ++sub) {
+            if (ct0 + sub * 32 >= K) break;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float *ea = Es + (h * HS) * VQ_CT + sub * 32 + col;
+#pragma unroll
+            for (int s = 0; s < HS; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ea[s * VQ_CT], xf[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cl = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int c = ct0 + cl;
+                const float dist = (xx - 2.f * acc[r]) + En[cl];
+                if (c < K && dist < best) { best = dist; besti = c; }
+            }
+        }
+    }
+    // combine the two half-waves (each saw half of the codes of every tile)
+    {
+        const float ob = __shfl_xor(best, 32, 64);
+        const int oi = __shfl_xor(besti, 32, 64);
+        if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    if (rv && h == 0) idx_out[row] = (int64_t)besti;
+
+    // gather + straight-through output + loss partial
+    float lsum = 0.f;
+#pragma unroll
+    for (int s = 0; s < HS; s += 4) {
+        const int d = h * HS + s;
+        if (rv && d < D) {
+            const float4 q = *reinterpret_cast<const float4 *>(embedT + (size_t)besti * D + d);
+            const float t0 = q.x - xf[s], t1 = q.y - xf[s + 1], t2 = q.z - xf[s + 2], t3 = q.w - xf[s + 3];
+            lsum += t0 * t0; lsum += t1 * t1; lsum += t2 * t2; lsum += t3 * t3;
+            if (out) {
+                float4 o;
+                o.x = xf[s] + t0; o.y = xf[s + 1] + t1; o.z = xf[s + 2] + t2; o.w = xf[s + 3] + t3;  // vqvae.py:73
+                *reinterpret_cast<float4 *>(out + row * ldo + d) = o;
+            }
+        }
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) wsum[wave] = lsum;
+    __syncthreads();
+    if (tid == 0 && loss_partial) loss_partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+
+    // EMA statistics (vqvae.py:55-56): one 4*D-byte contiguous atomic burst per latent vector
+    if (counts && sumsT) {
+        if (rv && h == 0) atomicAdd(counts + besti, 1.0f);
+        const int64_t wrow0 = (int64_t)blockIdx.x * VQ_ROWS + wave * 32;
+        if (D >= 64) {
+            for (int r = 0; r < 32; ++r) {
+                const int64_t rr = wrow0 + r;
+                if (rr >= M) break;
+                const int code = __shfl(besti, r, 64);
+                for (int d = lane; d < D; d += 64) atomicAdd(sumsT + (size_t)code * D + d, x[rr * ldx + d]);
+            }
+        } else {
+            const int rpi = 64 / D;  // rows per wave-instruction (D in {4,8,16,32})
+            const int rs = lane / D, d = lane % D;
+            for (int r = 0; r < 32; r += rpi) {
+                const int64_t rr = wrow0 + r + rs;
+                const int code = __shfl(besti, (r + rs) & 31, 64);
+                if (rs < rpi && rr < M) atomicAdd(sumsT + (size_t)code * D + d, x[rr * ldx + d]);
+            }
+        }
+    }
+}
+
+__global__ void vq_prepare_kernel(const float *__restrict__ embed, float *__restrict__ embedT,
+                                  float *__restrict__ enorm, int D, int K) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) {
+        const float e = embed[(size_t)d * K + k];
+        embedT[(size_t)k * D + d] = e;
+        s += e * e;
+    }
+    enorm[k] = s;
+}
+
+__global__ void vq_loss_kernel(const float *__restrict__ part, int nparts, float denom, float *__restrict__ diff) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) diff[0] = red[0] / denom;
+}
+
+__global__ void vq_bwd_kernel(const float *__restrict__ g_out, int ldg, const float *__restrict__ g_diff,
+                              const float *__restrict__ x, int ldx, const int64_t *__restrict__ idx,
+                              const float *__restrict__ embedT, int64_t M, int D, float inv_numel,
+                              float *__restrict__ dx, int lddx) {
+    const int D4 = D / 4;
+    const int64_t total = M * D4;
+    const float gN = g_diff ? g_diff[0] * inv_numel : 0.f;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = t / D4;
+        const int d = (int)(t - m * D4) * 4;
+        const float4 xv = *reinterpret_cast<const float4 *>(x + m * ldx + d);
+        const float4 q = *reinterpret_cast<const float4 *>(embedT + (size_t)idx[m] * D + d);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g_out) g = *reinterpret_cast<const float4 *>(g_out + m * ldg + d);
+        // autograd of vqvae.py:72-73: dx = g_out - (g_diff/numel) * (2 * (q - x))
+        float4 o;
+        o.x = g.x - gN * (2.f * (q.x - xv.x));
+        o.y = g.y - gN * (2.f * (q.y - xv.y));
+        o.z = g.z - gN * (2.f * (q.z - xv.z));
+        o.w = g.w - gN * (2.f * (q.w - xv.w));
+        *reinterpret_cast<float4 *>(dx + m * lddx + d) = o;
+    }
+}
+
+// vqvae.py:61-70, one workgroup: the Laplace-smoothing total n depends on every updated count
+__global__ __launch_bounds__(1024) void vq_ema_kernel(float *__restrict__ embed, float *__restrict__ cluster_size,
+                                                      float *__restrict__ embed_avg, const float *__restrict__ counts,
+                                                      const float *__restrict__ sumsT, int D, int K, float decay,
+                                                      float alpha, float eps, float keps) {
+    __shared__ float red[1024];
+    float local = 0.f;
+    for (int k = threadIdx.x; k < K; k += 1024) {
+        const float cs = fmaf(alpha, counts[k], cluster_size[k] * decay);
+        cluster_size[k] = cs;
+        local += cs;
+    }
+    red[threadIdx.x] = local;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const float n = red[0];
+    const float denom = n + keps;
+    const int total = D * K;
+    for (int t = threadIdx.x; t < total; t += 1024) {
+        const int d = t / K, k = t - d * K;
+        const float ea = fmaf(alpha, sumsT[(size_t)k * D + d], embed_avg[t] * decay);
+        embed_avg[t] = ea;
+        const float cs = (cluster_size[k] + eps) / denom * n;
+        embed[t] = ea / cs;
+    }
+}
+
+__global__ void vq_gather_kernel(const int64_t *__restrict__ idx, const float *__restrict__ embedT, int64_t M, int D,
+                                 int K, float *__restrict__ out, int ldo) {
+    const int D4 = D / 4;
+    const int64_t total = M * D4;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = t / D4;
+        const int d = (int)(t - m * D4) * 4;
+        int64_t c = idx[m];
+        c = c < 0 ? 0 : (c >= K ? K - 1 : c);  // never read outside the codebook
+        *reinterpret_cast<float4 *>(out + m * ldo + d) = *reinterpret_cast<const float4 *>(embedT + (size_t)c * D + d);
+    }
+}
+
+static inline int grid_for(int64_t work_items) {
+    int64_t b = (work_items + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace vq2
+
+using namespace vq2;
+
+extern "C" int vq2_vq_prepare(const float *embed, float *embedT, float *enorm, int32_t D, int32_t K,
+                              vq2_stream_t stream) {
+    VQ2_REQUIRE(embed && embedT && enorm && D > 0 && K > 0, "vq_prepare: bad arguments");
+    hipLaunchKernelGGL(vq_prepare_kernel, dim3((K + 255) / 256), dim3(256), 0, to_stream(stream), embed, embedT, enorm,
+                       D, K);
+    return check_launch("vq_prepare_kernel");
+}
+
+extern "C" size_t vq2_vq_fwd_workspace_floats(int64_t M) { return M <= 0 ? 0 : (size_t)((M + VQ_ROWS - 1) / VQ_ROWS); }
+
+extern "C" int vq2_vq_fwd(const float *x, int32_t ldx, const float *embed, const float *embedT, const float *enorm,
+                          int64_t M, int32_t D, int32_t K, int64_t *idx, float *out, int32_t ldo, float *loss_partial,
+                          float *counts, float *sumsT, vq2_stream_t stream) {
+    VQ2_REQUIRE(x && embed && embedT && enorm && idx, "vq_fwd: null pointer");
+    VQ2_REQUIRE(M > 0 && K > 0 && K % 4 == 0 && (D == 4 || D == 8 || D == 16 || D == 32 || D == 64),
+                "vq_fwd: need D in {4,8,16,32,64} and K %% 4 == 0 (D=%d K=%d)", D, K);
+    VQ2_REQUIRE(ldx >= D && ldx % 4 == 0 && (!out || (ldo >= D && ldo % 4 == 0)), "vq_fwd: bad pixel strides");
+    VQ2_REQUIRE(aligned16(x) && aligned16(embed) && aligned16(embedT) && (!out || aligned16(out)),
+                "vq_fwd: pointers must be 16-byte aligned");
+    VQ2_REQUIRE((counts == nullptr) == (sumsT == nullptr), "vq_fwd: counts and sumsT go together");
+    const unsigned grid = (unsigned)((M + VQ_ROWS - 1) / VQ_ROWS);
+    hipStream_t s = to_stream(stream);
+#define VQ2_LAUNCH_VQ(DP)                                                                                         \
+    hipLaunchKernelGGL(vq_fwd_kernel<DP>, dim3(grid), dim3(256), 0, s, x, ldx, embed, embedT, enorm, M, D, K, idx, \
+                       out, ldo, loss_partial, counts, sumsT)
+    if (D <= 16) VQ2_LAUNCH_VQ(16);
+    else if (D <= 32) VQ2_LAUNCH_VQ(32);
+    else VQ2_LAUNCH_VQ(64);
+#undef VQ2_LAUNCH_VQ
+    return check_launch("vq_fwd_kernel");
+}
+
+extern "C" int vq2_vq_loss(const float *loss_partial, int64_t M, int32_t D, float *diff, vq2_stream_t stream) {
+    VQ2_REQUIRE(loss_partial && diff && M > 0 && D > 0, "vq_loss: bad arguments");
+    const int nparts = (int)((M + VQ_ROWS - 1) / VQ_ROWS);
+    hipLaunchKernelGGL(vq_loss_kernel, dim3(1), dim3(256), 0, to_stream(stream), loss_partial, nparts,
+                       (float)((double)M * (double)D), diff);
+    return check_launch("vq_loss_kernel");
+}
+
+extern "C" int vq2_vq_bwd(const float *g_out, int32_t ldg, const float *g_diff, const float *x, int32_t ldx,
+                          const int64_t *idx, const float *embedT, int64_t M, int32_t D, int32_t K, float *dx,
+                          int32_t lddx, vq2_stream_t stream) {
+    VQ2_REQUIRE(x && idx && embedT && dx, "vq_bwd: null pointer");
+    VQ2_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && K > 0, "vq_bwd: bad dims");
+    VQ2_REQUIRE(ldx >= D && lddx >= D && (!g_out || ldg >= D) && ldx % 4 == 0 && lddx % 4 == 0 && ldg % 4 == 0,
+                "vq_bwd: bad pixel strides");
+    hipLaunchKernelGGL(vq_bwd_kernel, dim3(grid_for(M * (D / 4))), dim3(256), 0, to_stream(stream), g_out, ldg, g_diff,
+                       x, ldx, idx, embedT, M, D, (float)(1.0 / ((double)M * (double)D)), dx, lddx);
+    return check_launch("vq_bwd_kernel");
+}
+
+extern "C" int vq2_vq_ema_update(float *embed, float *cluster_size, float *embed_avg, const float *counts,
+                                 const float *sumsT, int32_t D, int32_t K, double decay, double eps,
+                                 vq2_stream_t stream) {
+    VQ2_REQUIRE(embed && cluster_size && embed_avg && counts && sumsT && D > 0 && K > 0, "vq_ema_update: bad arguments");
+    // Python forms (1 - decay) and n_embed * eps in double before the fp32 ops (vqvae.py:62,67)
+    const float alpha = (float)(1.0 - decay);
+    hipLaunchKernelGGL(vq_ema_kernel, dim3(1), dim3(1024), 0, to_stream(stream), embed, cluster_size, embed_avg, counts,
+                       sumsT, D, K, (float)decay, alpha, (float)eps, (float)((double)K * eps));
+    return check_launch("vq_ema_kernel");
+}
+
+extern "C" int vq2_vq_gather(const int64_t *idx, const float *embedT, int64_t M, int32_t D, int32_t K, float *out,
+                             int32_t ldo, vq2_stream_t stream) {
+    VQ2_REQUIRE(idx && embedT && out && M > 0 && D > 0 && D % 4 == 0 && K > 0 && ldo >= D && ldo % 4 == 0,
+                "vq_gather: bad arguments");
+    hipLaunchKernelGGL(vq_gather_kernel, dim3(grid_for(M * (D / 4))), dim3(256), 0, to_stream(stream), idx, embedT, M, D,
+                       K, out, ldo);
+    return check_launch("vq_gather_kernel");
+}

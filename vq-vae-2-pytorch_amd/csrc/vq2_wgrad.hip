@@ -1,0 +1,339 @@
+// Weight gradient of conv2d / conv-transpose2d (NHWC activations, reference-layout output).
+//
+//   dw[o][i][kh][kw] = sum_{n,ho,wo} G[n,ho,wo,o] * X[n, ho*s+kh-p, wo*s+kw-p, i]
+//
+//   conv  : X = (relu) input x,  G = dy                  -> dw in OIHW  (o = Co, i = Ci)
+//   convT : X = dy (the 2H x 2W tensor), G = (relu) x    -> dw in IOHW  (o = Ci, i = Co)
+//
+// This is a GEMM [O x M] * [M x K] (K = KH*KW*I) whose reduction dimension M = N*Ho*Wo is
+// huge and whose output is tiny, so the reduction is split over `S` workgroups per output
+// tile; every split writes its partial tile to a slab in the caller's workspace and a second
+// launch sums the slabs in a fixed order (bit-reproducible, no float atomics) and scatters
+// into the reference weight layout.  Both operands are consumed "reduction-major" straight
+// from NHWC memory: v_mfma_f32_32x32x2_f32 wants A[i][k] / B[k][j] with lanes along i / j,
+// and consecutive lanes read consecutive channels -> conflict-free ds_read_b32, no transposes.
+#include "vq2_common.h"
+
+namespace vq2 {
+
+struct WgradParams {
+    const float *x;  // image operand [N,H,W,ldx], I channels
+    const float *g;  // grad  operand [N,Ho,Wo,ldg], O channels
+    float *ws;       // [S][O][K] partial slabs
+    int N, H, W, I, ldx;
+    int Ho, Wo, O, ldg;
+    int KH, KW, stride, pad;
+    int K, M;
+    int rows_per_split;  // multiple of 32
+    int relu_x, relu_g;
+};
+
+constexpr int WG_BKR = 32;  // reduction rows (pixels) per staged chunk
+
+template <int WAVES_M, int WAVES_N, int MT, int NT>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
+    constexpr int BMO = WAVES_M * MT * 32;  // tile rows  (o)
+    constexpr int BNK = WAVES_N * NT * 32;  // tile cols  (k)
+    constexpr int G_C4 = BMO / 4, X_C4 = BNK / 4;
+    constexpr int G_RSTEP = 256 / G_C4, X_RSTEP = 256 / X_C4;
+    constexpr int G_LD = WG_BKR / G_RSTEP, X_LD = WG_BKR / X_RSTEP;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+    static_assert(G_C4 <= 256 && X_C4 <= 256 && G_LD >= 1 && X_LD >= 1, "tile/thread mapping");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Gs = smem;                       // [2][32][BMO]
+    float *Xs = smem + 2 * WG_BKR * BMO;    // [2][32][BNK]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int k0 = blockIdx.x * BNK;
+    const int o0 = blockIdx.y * BMO;
+    const int split = blockIdx.z;
+    const int m_begin = split * P.rows_per_split;
+    const int m_end = min(P.M, m_begin + P.rows_per_split);
+
+    // fixed per-thread column coordinates
+    const int g_c = o0 + (tid % G_C4) * 4;
+    const int g_r = tid / G_C4;
+    const int x_k = k0 + (tid % X_C4) * 4;
+    const int x_r = tid / X_C4;
+    const bool g_cv = g_c < P.O;
+    const bool x_kv = x_k < P.K;
+    int kh = 0, kw = 0, ci = 0;
+    if (x_kv) {
+        const int tap = x_k / P.I;
+        ci = x_k - tap * P.I;
+        kh = tap / P.KW;
+        kw = tap - kh * P.KW;
+    }
+    const int HoWo = P.Ho * P.Wo;
+
+    float4 rg[G_LD], rx[X_LD];
+    auto load_chunk = [&](int mbase) {
+#pragma unroll
+        for (int j = 0; j < G_LD; ++j) {
+            const int m = mbase + g_r + j * G_RSTEP;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g_cv && m < m_end) v = *reinterpret_cast<const float4 *>(P.g + (size_t)m * P.ldg + g_c);
+            rg[j] = P.relu_g ? relu4(v) : v;
+        }
+#pragma unroll
+        for (int j = 0; j < X_LD; ++j) {
+            const int m = mbase + x_r + j * X_RSTEP;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (x_kv && m < m_end) {
+                const int n = m / HoWo;
+                const int r = m - n * HoWo;
+                const int ho = r / P.Wo;
+                const int wo = r - ho * P.Wo;
+                const int ih = ho * P.stride - P.pad + kh;
+                const int iw = wo * P.stride - P.pad + kw;
+                if ((unsigned)ih < (unsigned)P.H && (unsigned)iw < (unsigned)P.W)
+                    v = *reinterpret_cast<const float4 *>(P.x + ((size_t)(n * P.H + ih) * P.W + iw) * P.ldx + ci);
+            }
+            rx[j] = P.relu_x ? relu4(v) : v;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        float *gs = Gs + buf * WG_BKR * BMO;
+        float *xs = Xs + buf * WG_BKR * BNK;
+#pragma unroll
+        for (int j = 0; j < G_LD; ++j)
+            *reinterpret_cast<float4 *>(gs + (g_r + j * G_RSTEP) * BMO + (tid % G_C4) * 4) = rg[j];
+#pragma unroll
+        for (int j = 0; j < X_LD; ++j)
+            *reinterpret_cast<float4 *>(xs + (x_r + j * X_RSTEP) * BNK + (tid % X_C4) * 4) = rx[j];
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nchunks = (m_end - m_begin + WG_BKR - 1) / WG_BKR;
+    if (nchunks > 0) {
+        load_chunk(m_begin);
+        store_chunk(0);
+    }
+    __syncthreads();
+    const int fr = lane & 31, fk = lane >> 5;
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) load_chunk(m_begin + (c + 1) * WG_BKR);
+        const float *gs = Gs + buf * WG_BKR * BMO + fk * BMO + wm * MT * 32 + fr;
+        const float *xs = Xs + buf * WG_BKR * BNK + fk * BNK + wn * NT * 32 + fr;
+#pragma unroll
+        for (int kk = 0; kk < WG_BKR / 2; ++kk) {
+            float fa[MT], fb[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[i] = gs[kk * 2 * BMO + i * 32];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[j] = xs[kk * 2 * BNK + j * 32];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (c + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // partial tile -> slab [split][o][k]
+    float *slab = P.ws + (size_t)split * P.O * P.K;
+    const int colq = lane & 31, rowq = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int k = k0 + (wn * NT + j) * 32 + colq;
+        if (k >= P.K) continue;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int ob = o0 + (wm * MT + i) * 32 + rowq;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = ob + (r & 3) + 8 * (r >> 2);
+                if (o < P.O) slab[(size_t)o * P.K + k] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+// sum slabs in split order; scatter [o][tap][i] (padded O x I) -> reference layout [Or][Ir][tap]
+__global__ void wgrad_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, int O, int I, int Or, int Ir,
+                                    int taps, int S) {
+    const int K = taps * I;
+    const int total = O * K;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const int o = t / K, k = t - o * K;
+        const int tap = k / I, i = k - tap * I;
+        if (o >= Or || i >= Ir) continue;
+        float s = 0.f;
+        for (int z = 0; z < S; ++z) s += ws[(size_t)z * total + t];
+        dw[((size_t)o * Ir + i) * taps + tap] = s;
+    }
+}
+
+struct WgradPlan {
+    int O, I, K, M, S, rows_per_split, bmo;
+};
+
+static WgradPlan plan_wgrad(const vq2_conv_desc *d) {
+    WgradPlan p;
+    if (!d->transposed) {
+        p.O = d->Co; p.I = d->Ci;
+        const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+        p.M = d->N * Ho * Wo;
+    } else {
+        p.O = d->Ci; p.I = d->Co;
+        p.M = d->N * d->H * d->W;
+    }
+    p.K = d->KH * d->KW * p.I;
+    p.bmo = p.O > 64 ? 128 : (p.O > 32 ? 64 : 32);
+    const int bnk = p.bmo == 32 ? 256 : 128;
+    const int tiles = ((p.K + bnk - 1) / bnk) * ((p.O + p.bmo - 1) / p.bmo);
+    int S = (1024 + tiles - 1) / tiles;              // aim at >= 4 workgroups per CU
+    const int max_s = (p.M + 255) / 256;             // at least 8 chunks of 32 rows per split
+    if (S > max_s) S = max_s;
+    if (S > 512) S = 512;
+    if (S < 1) S = 1;
+    int rps = (p.M + S - 1) / S;
+    rps = (rps + 31) / 32 * 32;
+    p.S = (p.M + rps - 1) / rps;
+    p.rows_per_split = rps;
+    return p;
+}
+
+template <int WAVES_M, int WAVES_N, int MT, int NT>
+static int launch_wgrad(const WgradParams &P, int S, hipStream_t s) {
+    constexpr int BMO = WAVES_M * MT * 32, BNK = WAVES_N * NT * 32;
+    const size_t lds = (size_t)2 * WG_BKR * (BMO + BNK) * sizeof(float);
+    auto kern = wgrad_kernel<WAVES_M, WAVES_N, MT, NT>;
+    allow_big_lds(kern, lds);
+    dim3 grid((P.K + BNK - 1) / BNK, (P.O + BMO - 1) / BMO, S);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, P);
+    return check_launch("wgrad_kernel");
+}
+
+// ------------------------------------------------------------------ column sums (bias gradient)
+constexpr int CS_ROWS_PER_BLOCK = 2048;
+
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ x, int64_t rows, int C, int ld,
+                                                             float *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [nrg][C]
+    const int C4 = C / 4;
+    const int nrg = 256 / C4 > 0 ? 256 / C4 : 1;
+    const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS_PER_BLOCK;
+    const int64_t r1 = r0 + CS_ROWS_PER_BLOCK < rows ? r0 + CS_ROWS_PER_BLOCK : rows;
+    for (int cbase = 0; cbase < C4; cbase += 256) {
+        const int c4 = cbase + (int)(threadIdx.x % (C4 < 256 ? C4 : 256));
+        const int rg = threadIdx.x / (C4 < 256 ? C4 : 256);
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rg < nrg && c4 < C4) {
+            for (int64_t r = r0 + rg; r < r1; r += nrg) {
+                const float4 v = *reinterpret_cast<const float4 *>(x + r * ld + c4 * 4);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            *reinterpret_cast<float4 *>(red + (size_t)rg * C + c4 * 4) = a;
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 256) {
+            if (c / 4 >= cbase && c / 4 < cbase + 256) {
+                float s = 0.f;
+                for (int g = 0; g < nrg; ++g) s += red[(size_t)g * C + c];
+                part[(size_t)blockIdx.x * C + c] = s;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void colsum_final_kernel(const float *__restrict__ part, int nblocks, int C, float *__restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * C + c];
+    out[c] = s;
+}
+
+}  // namespace vq2
+
+using namespace vq2;
+
+extern "C" size_t vq2_conv_wgrad_workspace_bytes(const vq2_conv_desc *d) {
+    if (!d || d->N <= 0 || d->Ci <= 0 || d->Co <= 0) return 0;
+    const WgradPlan p = plan_wgrad(d);
+    return (size_t)p.S * p.O * p.K * sizeof(float);
+}
+
+extern "C" int vq2_conv_wgrad(const vq2_conv_desc *d, int flags, const float *x, const float *dy, float *dw, void *ws,
+                              size_t ws_bytes, vq2_stream_t stream) {
+    VQ2_REQUIRE(d && x && dy && dw && ws, "conv_wgrad: null pointer");
+    VQ2_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Ci > 0 && d->Co > 0 && d->Ci % 4 == 0 && d->Co % 4 == 0,
+                "conv_wgrad: bad dims");
+    VQ2_REQUIRE(d->ldx >= d->Ci && d->ldy >= d->Co && d->ldx % 4 == 0 && d->ldy % 4 == 0, "conv_wgrad: bad strides");
+    VQ2_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(ws), "conv_wgrad: pointers must be 16-byte aligned");
+    if (d->transposed)
+        VQ2_REQUIRE(d->KH == 4 && d->KW == 4 && d->stride == 2 && d->pad == 1, "conv_wgrad: convT must be k4 s2 p1");
+    else
+        VQ2_REQUIRE(d->KH == d->KW && d->KH >= 1 && d->KH <= 7 && (d->stride == 1 || d->stride == 2) && d->pad >= 0,
+                    "conv_wgrad: unsupported conv geometry");
+    const WgradPlan p = plan_wgrad(d);
+    VQ2_REQUIRE(ws_bytes >= (size_t)p.S * p.O * p.K * sizeof(float), "conv_wgrad: workspace too small");
+    WgradParams P{};
+    P.ws = static_cast<float *>(ws);
+    P.KH = d->KH; P.KW = d->KW; P.stride = d->stride; P.pad = d->pad;
+    P.O = p.O; P.I = p.I; P.K = p.K; P.M = p.M; P.rows_per_split = p.rows_per_split;
+    P.N = d->N;
+    if (!d->transposed) {
+        P.x = x; P.ldx = d->ldx; P.H = d->H; P.W = d->W;
+        P.g = dy; P.ldg = d->ldy;
+        P.Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1; P.Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+        P.relu_x = (flags & VQ2_RELU_IN) != 0; P.relu_g = 0;
+    } else {
+        P.x = dy; P.ldx = d->ldy; P.H = 2 * d->H; P.W = 2 * d->W;
+        P.g = x; P.ldg = d->ldx;
+        P.Ho = d->H; P.Wo = d->W;
+        P.relu_x = 0; P.relu_g = (flags & VQ2_RELU_IN) != 0;
+    }
+    VQ2_REQUIRE((int64_t)P.N * P.H * P.W * P.ldx < ((int64_t)1 << 31) && (int64_t)P.M * P.ldg < ((int64_t)1 << 31),
+                "conv_wgrad: tensor exceeds 2^31 elements");
+    hipStream_t s = to_stream(stream);
+    int e;
+    if (p.bmo == 128) e = launch_wgrad<2, 2, 2, 2>(P, p.S, s);       // 128(o) x 128(k)
+    else if (p.bmo == 64) e = launch_wgrad<1, 4, 2, 1>(P, p.S, s);   // 64 x 128
+    else e = launch_wgrad<1, 4, 1, 2>(P, p.S, s);                    // 32 x 256
+    if (e) return e;
+    const int total = p.O * p.K;
+    const int blocks = (total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048;
+    const int cir = d->Cir ? d->Cir : d->Ci, cor = d->Cor ? d->Cor : d->Co;
+    const int Or = d->transposed ? cir : cor, Ir = d->transposed ? cor : cir;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, P.ws, dw, p.O, p.I, Or, Ir, d->KH * d->KW,
+                       p.S);
+    return check_launch("wgrad_reduce_kernel");
+}
+
+extern "C" size_t vq2_colsum_workspace_bytes(int64_t rows, int32_t C) {
+    if (rows <= 0 || C <= 0) return 0;
+    const int64_t nb = (rows + CS_ROWS_PER_BLOCK - 1) / CS_ROWS_PER_BLOCK;
+    return (size_t)nb * C * sizeof(float);
+}
+
+extern "C" int vq2_colsum(const float *dy, int64_t rows, int32_t C, int32_t ld, float *db, void *ws, size_t ws_bytes,
+                          vq2_stream_t stream) {
+    VQ2_REQUIRE(dy && db && ws, "colsum: null pointer");
+    VQ2_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && ld >= C && ld % 4 == 0 && C <= 4096, "colsum: bad shape");
+    VQ2_REQUIRE(aligned16(dy), "colsum: dy must be 16-byte aligned");
+    const int64_t nb = (rows + CS_ROWS_PER_BLOCK - 1) / CS_ROWS_PER_BLOCK;
+    VQ2_REQUIRE(ws_bytes >= (size_t)nb * C * sizeof(float), "colsum: workspace too small");
+    const int C4 = C / 4;
+    const int nrg = 256 / C4 > 0 ? 256 / C4 : 1;
+    hipStream_t s = to_stream(stream);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nb), dim3(256), (size_t)nrg * C * sizeof(float), s, dy, rows,
+                       C, ld, static_cast<float *>(ws));
+    if (int e = check_launch("colsum_partial_kernel")) return e;
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s, static_cast<const float *>(ws),
+                       (int)nb, C, db);
+    return check_launch("colsum_final_kernel");
+}

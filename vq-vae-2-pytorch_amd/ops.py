@@ -1,0 +1,573 @@
+"""torch.autograd.Function wrappers over the C ABI of libvq2.so (include/vq2.h).
+
+Activations inside this module are NHWC tensors of shape [N,H,W,C] whose last dim is
+contiguous and whose pixel stride `ld = t.stride(2)` may exceed C (a channel slice of a
+wider buffer).  PyTorch is used for device memory, streams and autograd bookkeeping only;
+every FLOP and every byte moved on this path is a libvq2 kernel.
+"""
+from dataclasses import dataclass
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+
+from ._lib import lib, check, ConvDesc
+
+VQ2_RELU_IN = 1
+VQ2_RELU_OUT = 2
+PACK_FWD = 0
+PACK_DGRAD = 1
+
+# bumped by FusedAdam (it updates weights through raw pointers, which does not touch
+# tensor._version); part of the packed-weight cache key
+WEIGHT_EPOCH = [0]
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def ceil4(c):
+    return (c + 3) // 4 * 4
+
+
+def _require_cuda(t, what):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
+        raise RuntimeError(f"vqvae2_amd: {what} must be a float32 tensor on the MI355X (got "
+                           f"{getattr(t, 'dtype', type(t))} on {getattr(t, 'device', '?')}); "
+                           "this package has no CPU path")
+
+
+def is_nhwc_dense(t):
+    """[N,H,W,C] with contiguous channels and a uniform pixel stride, 16-byte aligned."""
+    if t.dim() != 4 or t.stride(3) != 1:
+        return False
+    n, h, w, c = t.shape
+    ld = t.stride(2)
+    if w == 1:
+        ld = t.stride(1) if h > 1 else (t.stride(0) if n > 1 else c)
+    return (ld >= c and ld % 4 == 0 and (w == 1 or t.stride(2) == ld) and (h == 1 or t.stride(1) == w * ld)
+            and (n == 1 or t.stride(0) == h * w * ld) and t.data_ptr() % 16 == 0)
+
+
+def ld_of(t):
+    n, h, w, c = t.shape
+    if w > 1:
+        return t.stride(2)
+    if h > 1:
+        return t.stride(1)
+    if n > 1:
+        return t.stride(0)
+    return c
+
+
+def as_nhwc(t):
+    """Return t if it already is a dense NHWC view (any pixel stride), else a packed copy."""
+    _require_cuda(t, "activation")
+    if is_nhwc_dense(t):
+        return t
+    return t.contiguous()  # exotic layout handed in by foreign code; never hit on the stage-1 path
+
+
+def packed(t):
+    """Dense NHWC view -> pixel stride == C (slice-copy kernel when it is a channel slice)."""
+    if t.is_contiguous():
+        return t
+    t = as_nhwc(t)
+    if t.is_contiguous():
+        return t
+    n, h, w, c = t.shape
+    out = torch.empty((n, h, w, c), device=t.device, dtype=torch.float32)
+    check(lib.vq2_slice_copy(_p(t), ld_of(t), _p(out), c, n * h * w, c, 0, _stream()), "slice_copy")
+    return out
+
+
+# ----------------------------------------------------------------------------- conv plumbing
+@dataclass(frozen=True)
+class ConvSpec:
+    transposed: bool
+    cin: int
+    cout: int
+    k: int
+    stride: int
+    pad: int
+
+    @property
+    def ci(self):
+        return ceil4(self.cin)
+
+    @property
+    def co(self):
+        return ceil4(self.cout)
+
+    def out_hw(self, h, w):
+        if self.transposed:
+            return 2 * h, 2 * w
+        return (h + 2 * self.pad - self.k) // self.stride + 1, (w + 2 * self.pad - self.k) // self.stride + 1
+
+
+def _desc(spec, n, h, w, ldx, ldy):
+    d = ConvDesc()
+    d.N, d.H, d.W, d.Ci, d.Co = n, h, w, spec.ci, spec.co
+    d.KH = d.KW = spec.k
+    d.stride, d.pad, d.transposed = spec.stride, spec.pad, int(spec.transposed)
+    d.ldx, d.ldy = ldx, ldy
+    d.Cir, d.Cor = spec.cin, spec.cout
+    return d
+
+
+_pack_cache = {}
+
+
+def packed_weight(spec, weight, which):
+    """Kernel-layout copy of a reference-layout weight, cached until the weight changes."""
+    key = (id(weight), which)
+    ver = (weight.data_ptr(), weight._version, WEIGHT_EPOCH[0], spec)
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    _require_cuda(weight, "weight")
+    wsrc = weight.detach()
+    if not wsrc.is_contiguous():
+        wsrc = wsrc.contiguous()
+    n = spec.ci * spec.co * spec.k * spec.k
+    buf = hit[1] if (hit is not None and hit[1].numel() == n) else torch.empty(n, device=weight.device,
+                                                                               dtype=torch.float32)
+    d = _desc(spec, 1, max(spec.k, 2), max(spec.k, 2), spec.ci, spec.co)
+    check(lib.vq2_pack_weight(C.byref(d), which, _p(wsrc), _p(buf), _stream()), "pack_weight")
+    _pack_cache[key] = (ver, buf)
+    return buf
+
+
+def conv_forward(spec, x, weight, bias, flags=0, residual=None, out=None):
+    n, h, w, c = x.shape
+    if c != spec.ci:
+        raise RuntimeError(f"conv_forward: input has {c} channels, expected {spec.ci}")
+    ho, wo = spec.out_hw(h, w)
+    if out is None:
+        out = torch.empty((n, ho, wo, spec.co), device=x.device, dtype=torch.float32)
+    elif tuple(out.shape) != (n, ho, wo, spec.co) or not is_nhwc_dense(out):
+        raise RuntimeError("conv_forward: bad `out` buffer")
+    d = _desc(spec, n, h, w, ld_of(x), ld_of(out))
+    wp = packed_weight(spec, weight, PACK_FWD)
+    ldres = ld_of(residual) if residual is not None else 0
+    check(lib.vq2_conv_fwd(C.byref(d), flags, _p(x), _p(wp), _p(bias), _p(residual), ldres, _p(out), _stream()),
+          "conv_fwd")
+    return out
+
+
+def conv_dgrad(spec, xshape, dy, weight, mask=None, residual=None, out=None):
+    n, h, w, _ = xshape
+    if out is None:
+        out = torch.empty((n, h, w, spec.ci), device=dy.device, dtype=torch.float32)
+    d = _desc(spec, n, h, w, spec.ci, ld_of(dy))
+    wp = packed_weight(spec, weight, PACK_DGRAD)
+    check(lib.vq2_conv_dgrad(C.byref(d), _p(dy), _p(wp), _p(mask), ld_of(mask) if mask is not None else 0,
+                             _p(residual), ld_of(residual) if residual is not None else 0, _p(out), ld_of(out),
+                             _stream()), "conv_dgrad")
+    return out
+
+
+def conv_wgrad(spec, x, dy, relu_in, weight_like):
+    n, h, w, _ = x.shape
+    d = _desc(spec, n, h, w, ld_of(x), ld_of(dy))
+    nbytes = lib.vq2_conv_wgrad_workspace_bytes(C.byref(d))
+    ws = torch.empty(max(nbytes // 4, 4), device=x.device, dtype=torch.float32)
+    slot = getattr(weight_like, "_vq2_grad", None)  # ParamArena: gradient lands in the flat buffer
+    dw = slot.view_as(slot) if slot is not None else torch.empty_like(weight_like,
+                                                                      memory_format=torch.contiguous_format)
+    check(lib.vq2_conv_wgrad(C.byref(d), VQ2_RELU_IN if relu_in else 0, _p(x), _p(dy), _p(dw), _p(ws), nbytes,
+                             _stream()), "conv_wgrad")
+    return dw
+
+
+def bias_grad(dy, cout, bias_like=None):
+    n, h, w, c = dy.shape
+    rows = n * h * w
+    nbytes = lib.vq2_colsum_workspace_bytes(rows, c)
+    ws = torch.empty(max(nbytes // 4, 4), device=dy.device, dtype=torch.float32)
+    slot = getattr(bias_like, "_vq2_grad", None) if bias_like is not None else None
+    if slot is not None and cout == c:
+        db = slot.view_as(slot)
+    else:
+        db = torch.empty(c, device=dy.device, dtype=torch.float32)
+    check(lib.vq2_colsum(_p(dy), rows, c, ld_of(dy), _p(db), _p(ws), nbytes, _stream()), "colsum")
+    if cout != c:
+        db = db[:cout]
+        if slot is not None:  # padded 3-channel case: copy the real entries into the arena slot
+            check(lib.vq2_axpby(_p(db), _p(db), 0.0, _p(slot), cout, _stream()), "axpby")
+            db = slot.view_as(slot)
+    return db
+
+
+def relu_bwd(dy, y):
+    """g = dy * (y > 0) for dense NHWC operands of any pixel stride."""
+    n, h, w, c = dy.shape
+    g = torch.empty((n, h, w, c), device=dy.device, dtype=torch.float32)
+    check(lib.vq2_relu_bwd(_p(dy), ld_of(dy), _p(y), ld_of(y), _p(g), c, n * h * w, c, _stream()), "relu_bwd")
+    return g
+
+
+def add_(a, b, alpha=1.0):
+    """a + alpha*b into a fresh packed tensor (own kernel; used for autograd fan-out sums)."""
+    a, b = packed(a), packed(b)
+    out = torch.empty_like(a)
+    check(lib.vq2_axpby(_p(a), _p(b), float(alpha), _p(out), a.numel(), _stream()), "axpby")
+    return out
+
+
+# ----------------------------------------------------------------------------- layout boundary
+class NchwToNhwc(Function):
+    """[N,C,H,W] (any strides) -> packed NHWC [N,H,W,ceil4(C)] (zero padded)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_cuda(x, "input")
+        n, c, h, w = x.shape
+        ctx.c = c
+        xc = x if x.is_contiguous() else x.contiguous()
+        out = torch.empty((n, h, w, ceil4(c)), device=x.device, dtype=torch.float32)
+        check(lib.vq2_nchw_to_nhwc(_p(xc), _p(out), n, c, h, w, ceil4(c), _stream()), "nchw_to_nhwc")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = as_nhwc(g)
+        n, h, w, cp = g.shape
+        out = torch.empty((n, ctx.c, h, w), device=g.device, dtype=torch.float32)
+        check(lib.vq2_nhwc_to_nchw(_p(g), _p(out), n, ctx.c, h, w, ld_of(g), _stream()), "nhwc_to_nchw")
+        return out
+
+
+class NhwcToNchw(Function):
+    """NHWC [N,H,W,Cp] -> contiguous NCHW [N,C,H,W] dropping padded channels."""
+
+    @staticmethod
+    def forward(ctx, x, c):
+        n, h, w, cp = x.shape
+        ctx.cp = cp
+        out = torch.empty((n, c, h, w), device=x.device, dtype=torch.float32)
+        check(lib.vq2_nhwc_to_nchw(_p(x), _p(out), n, c, h, w, ld_of(x), _stream()), "nhwc_to_nchw")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n, c, h, w = g.shape
+        gc = g if g.is_contiguous() else g.contiguous()
+        out = torch.empty((n, h, w, ctx.cp), device=g.device, dtype=torch.float32)
+        check(lib.vq2_nchw_to_nhwc(_p(gc), _p(out), n, c, h, w, ctx.cp, _stream()), "nchw_to_nhwc")
+        return out, None
+
+
+def to_nhwc(x):
+    """Module-boundary input: NCHW tensor -> internal NHWC (zero-copy when x is channels-last)."""
+    _require_cuda(x, "input")
+    if x.dim() != 4:
+        raise RuntimeError("expected a 4-D NCHW tensor")
+    c = x.shape[1]
+    if c % 4 == 0:
+        v = x.permute(0, 2, 3, 1)
+        if is_nhwc_dense(v):
+            return v
+    return NchwToNhwc.apply(x)
+
+
+def from_nhwc(y, c):
+    """Internal NHWC -> NCHW-shaped result (zero-copy channels-last view when C % 4 == 0)."""
+    if y.shape[3] == c:
+        return y.permute(0, 3, 1, 2)
+    return NhwcToNchw.apply(y, c)
+
+
+class ReluFn(Function):
+    """Stand-alone ReLU (only used when a ReLU cannot be fused into a neighbouring conv)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = as_nhwc(x)
+        y = relu_bwd(x, x)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return relu_bwd(as_nhwc(g), y)
+
+
+# ----------------------------------------------------------------------------- fused conv op
+class ConvFn(Function):
+    """y = [relu]( conv|convT([relu] x) + b [+ residual] ), NHWC."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, spec, flags, out):
+        x = as_nhwc(x)
+        if residual is not None:
+            residual = as_nhwc(residual)
+        y = conv_forward(spec, x, weight, bias, flags, residual, out)
+        ctx.spec, ctx.flags = spec, flags
+        ctx.has_res = residual is not None
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight, y if (flags & VQ2_RELU_OUT) else None, bias)
+        if out is not None:
+            y = y.view_as(y)  # fresh tensor object aliasing the caller's buffer
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y, bias = ctx.saved_tensors
+        spec, flags = ctx.spec, ctx.flags
+        g = as_nhwc(dy)
+        if flags & VQ2_RELU_OUT:
+            g = relu_bwd(g, y)
+        relu_in = bool(flags & VQ2_RELU_IN)
+        dx = dw = db = dres = None
+        if ctx.needs_input_grad[0]:
+            dx = conv_dgrad(spec, x.shape, g, weight, mask=x if relu_in else None)
+        if ctx.needs_input_grad[1]:
+            dw = conv_wgrad(spec, x, g, relu_in, weight)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = bias_grad(g, spec.cout, bias)
+        if ctx.has_res and ctx.needs_input_grad[3]:
+            dres = g
+        return dx, dw, db, dres, None, None, None
+
+
+def conv_op(x, weight, bias, spec, relu_in=False, relu_out=False, residual=None, out=None):
+    flags = (VQ2_RELU_IN if relu_in else 0) | (VQ2_RELU_OUT if relu_out else 0)
+    return ConvFn.apply(x, weight, bias, residual, spec, flags, out)
+
+
+class ResBlockFn(Function):
+    """vqvae.py:81-96 as two launches forward and four backward:
+        r = relu(conv3x3(relu(x)) + b1)            (ReLU in + ReLU out fused)
+        y = [relu]( conv1x1(r) + b2 + x )          (residual, optional trailing ReLU fused)
+    backward fuses both ReLU masks and the skip-path add into the dgrad epilogues."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, spec1, spec2, relu_out, out):
+        x = as_nhwc(x)
+        r = conv_forward(spec1, x, w1, b1, VQ2_RELU_IN | VQ2_RELU_OUT)
+        y = conv_forward(spec2, r, w2, b2, VQ2_RELU_OUT if relu_out else 0, residual=x, out=out)
+        ctx.spec1, ctx.spec2, ctx.relu_out = spec1, spec2, relu_out
+        ctx.save_for_backward(x, r, w1, w2, y if relu_out else None, b1, b2)
+        if out is not None:
+            y = y.view_as(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, r, w1, w2, y, b1, b2 = ctx.saved_tensors
+        s1, s2 = ctx.spec1, ctx.spec2
+        g = as_nhwc(dy)
+        if ctx.relu_out:
+            g = relu_bwd(g, y)
+        # through conv1x1 and the inner ReLU (mask r > 0)
+        dh = conv_dgrad(s2, r.shape, g, w2, mask=r)
+        dw2 = conv_wgrad(s2, r, g, False, w2) if ctx.needs_input_grad[3] else None
+        db2 = bias_grad(g, s2.cout, b2) if ctx.needs_input_grad[4] else None
+        # through conv3x3 and the outer ReLU (mask x > 0), plus the skip gradient
+        dx = conv_dgrad(s1, x.shape, dh, w1, mask=x, residual=g) if ctx.needs_input_grad[0] else None
+        dw1 = conv_wgrad(s1, x, dh, True, w1) if ctx.needs_input_grad[1] else None
+        db1 = bias_grad(dh, s1.cout, b1) if ctx.needs_input_grad[2] else None
+        return dx, dw1, db1, dw2, db2, None, None, None, None
+
+
+class CatViewFn(Function):
+    """torch.cat([a, b], channel) where a and b were *produced into* adjacent channel slices
+    of `buf` (vqvae.py:218,233): forward is free, backward hands out slices of the gradient."""
+
+    @staticmethod
+    def forward(ctx, a, b, buf):
+        ctx.ca = a.shape[3]
+        return buf.view_as(buf)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = as_nhwc(g)
+        return g[..., :ctx.ca], g[..., ctx.ca:], None
+
+
+class FanOutFn(Function):
+    """One tensor consumed twice (enc_b -> enc_t and the concat, vqvae.py:225,233; quant_t ->
+    dec_t and upsample_t, vqvae.py:232,217).  Forward: two aliases; backward: one add kernel."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if g1 is None:
+            return g2
+        if g2 is None:
+            return g1
+        return add_(as_nhwc(g1), as_nhwc(g2))
+
+
+class AddScalarsFn(Function):
+    """diff_t + diff_b (vqvae.py:240) on the device without an ATen launch."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        out = torch.empty(1, device=a.device, dtype=torch.float32)
+        check(lib.vq2_axpby(_p(a), _p(b), 1.0, _p(out), 1, _stream()), "axpby")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.reshape(()), g.reshape(())
+
+
+# ----------------------------------------------------------------------------- Quantize
+def vq_prepare(embed):
+    d, k = embed.shape
+    embed_t = torch.empty((k, d), device=embed.device, dtype=torch.float32)
+    enorm = torch.empty(k, device=embed.device, dtype=torch.float32)
+    check(lib.vq2_vq_prepare(_p(embed), _p(embed_t), _p(enorm), d, k, _stream()), "vq_prepare")
+    return embed_t, enorm
+
+
+class QuantizeFn(Function):
+    """vqvae.py:42-75 minus the EMA update (done by the module after the all-reduce).
+    Returns (ste_out [N,H,W,D], diff 0-dim, idx int64 [N,H,W], stats) where stats is the flat
+    fp32 buffer [counts (K) | sumsT (K*D)] of vqvae.py:55-56 (None in eval mode)."""
+
+    @staticmethod
+    def forward(ctx, x, embed, want_stats, stats_buf, out_buf):
+        x = as_nhwc(x)
+        n, h, w, d = x.shape
+        k = embed.shape[1]
+        m = n * h * w
+        embed_t, enorm = vq_prepare(embed)
+        idx = torch.empty((n, h, w), device=x.device, dtype=torch.int64)
+        if out_buf is None:
+            out = torch.empty((n, h, w, d), device=x.device, dtype=torch.float32)
+        else:
+            if tuple(out_buf.shape) != (n, h, w, d) or not is_nhwc_dense(out_buf):
+                raise RuntimeError("QuantizeFn: bad output buffer")
+            out = out_buf.view_as(out_buf)
+        part = torch.empty(lib.vq2_vq_fwd_workspace_floats(m), device=x.device, dtype=torch.float32)
+        stats = counts = sums_t = None
+        if want_stats:
+            if stats_buf is not None:
+                if stats_buf.numel() != k + k * d or not stats_buf.is_contiguous():
+                    raise RuntimeError("QuantizeFn: stats buffer must be contiguous with K + K*D floats")
+                stats = stats_buf.view_as(stats_buf)  # caller zeroes it
+            else:
+                stats = torch.zeros(k + k * d, device=x.device, dtype=torch.float32)
+            counts, sums_t = stats[:k], stats[k:]
+        check(lib.vq2_vq_fwd(_p(x), ld_of(x), _p(embed), _p(embed_t), _p(enorm), m, d, k, _p(idx), _p(out), ld_of(out),
+                             _p(part), _p(counts), _p(sums_t), _stream()), "vq_fwd")
+        diff = torch.empty((), device=x.device, dtype=torch.float32)
+        check(lib.vq2_vq_loss(_p(part), m, d, _p(diff), _stream()), "vq_loss")
+        ctx.save_for_backward(x, idx, embed_t)
+        ctx.k = k
+        ctx.mark_non_differentiable(idx)
+        if stats is not None:
+            ctx.mark_non_differentiable(stats)
+        return out, diff, idx, stats
+
+    @staticmethod
+    def backward(ctx, g_out, g_diff, _gi, _gs):
+        x, idx, embed_t = ctx.saved_tensors
+        n, h, w, d = x.shape
+        if g_out is not None:
+            g_out = as_nhwc(g_out)
+        if g_diff is not None and not g_diff.is_contiguous():
+            g_diff = g_diff.contiguous()
+        dx = torch.empty((n, h, w, d), device=x.device, dtype=torch.float32)
+        check(lib.vq2_vq_bwd(_p(g_out), ld_of(g_out) if g_out is not None else d, _p(g_diff), _p(x), ld_of(x),
+                             _p(idx), _p(embed_t), n * h * w, d, ctx.k, _p(dx), d, _stream()), "vq_bwd")
+        return dx, None, None, None, None
+
+
+def vq_ema_update(embed, cluster_size, embed_avg, stats, decay, eps):
+    d, k = embed.shape
+    counts, sums_t = stats[:k], stats[k:]
+    check(lib.vq2_vq_ema_update(_p(embed), _p(cluster_size), _p(embed_avg), _p(counts), _p(sums_t), d, k,
+                                float(decay), float(eps), _stream()), "vq_ema_update")
+
+
+def vq_gather(idx, embed):
+    """embed_code (vqvae.py:77-78): idx [...] int64 -> [..., D]."""
+    d, k = embed.shape
+    embed_t, _ = vq_prepare(embed)
+    idx_c = idx.contiguous()
+    m = idx_c.numel()
+    out = torch.empty((*idx.shape, d), device=embed.device, dtype=torch.float32)
+    check(lib.vq2_vq_gather(_p(idx_c), _p(embed_t), m, d, k, _p(out), d, _stream()), "vq_gather")
+    return out
+
+
+# ----------------------------------------------------------------------------- loss
+def _scale_by(src, scalar, alpha=1.0):
+    """src * scalar[0] * alpha with the scalar read on the device (no host sync)."""
+    out = torch.empty_like(src)
+    sc = scalar.reshape(1) if scalar.is_contiguous() else scalar.contiguous().reshape(1)
+    check(lib.vq2_scale(_p(src), _p(sc), float(alpha), _p(out), src.numel(), _stream()), "scale")
+    return out
+
+
+class MseLossFn(Function):
+    """nn.MSELoss() (train_vqvae.py:31,83); the gradient 2(a-b)/n is produced in the same pass."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _require_cuda(a, "mse input")
+        ac = a if a.is_contiguous() else a.contiguous()
+        bc = b if b.is_contiguous() else b.contiguous()
+        n = ac.numel()
+        loss = torch.empty((), device=a.device, dtype=torch.float32)
+        grad = torch.empty_like(ac) if ctx.needs_input_grad[0] else None
+        ws = torch.empty(lib.vq2_mse_workspace_bytes(n) // 4, device=a.device, dtype=torch.float32)
+        check(lib.vq2_mse_fwd_bwd(_p(ac), _p(bc), n, n, None, _p(loss), _p(grad), _p(ws), ws.numel() * 4, _stream()),
+              "mse_fwd_bwd")
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return (None if grad is None else _scale_by(grad, g)), None
+
+
+def mse_loss(a, b):
+    return MseLossFn.apply(a, b)
+
+
+class Stage1LossFn(Function):
+    """loss = MSE(dec, img) + 0.25 * diff.mean()  (train_vqvae.py:83-85) -> (loss, recon, latent)."""
+
+    @staticmethod
+    def forward(ctx, dec, diff, img, weight):
+        _require_cuda(dec, "dec")
+        dc = dec if dec.is_contiguous() else dec.contiguous()
+        ic = img if img.is_contiguous() else img.contiguous()
+        n = dc.numel()
+        recon = torch.empty((), device=dec.device, dtype=torch.float32)
+        grad = torch.empty_like(dc) if ctx.needs_input_grad[0] else None
+        ws = torch.empty(lib.vq2_mse_workspace_bytes(n) // 4, device=dec.device, dtype=torch.float32)
+        check(lib.vq2_mse_fwd_bwd(_p(dc), _p(ic), n, n, None, _p(recon), _p(grad), _p(ws), ws.numel() * 4, _stream()),
+              "mse_fwd_bwd")
+        if diff.numel() != 1:
+            raise RuntimeError("stage1 loss expects the [1]-shaped latent loss of VQVAE.forward")
+        latent = diff.detach().reshape(())  # mean of a single element
+        loss = torch.empty((), device=dec.device, dtype=torch.float32)
+        check(lib.vq2_axpby(_p(recon), _p(latent.contiguous()), float(weight), _p(loss), 1, _stream()), "axpby")
+        ctx.save_for_backward(grad)
+        ctx.weight = weight
+        ctx.diff_shape = diff.shape
+        ctx.mark_non_differentiable(recon, latent)
+        return loss, recon, latent
+
+    @staticmethod
+    def backward(ctx, g, _gr, _gl):
+        (grad,) = ctx.saved_tensors
+        d_dec = None if grad is None else _scale_by(grad, g)
+        d_diff = _scale_by(torch.ones(ctx.diff_shape, device=g.device), g, ctx.weight) if ctx.needs_input_grad[1] else None
+        return d_dec, d_diff, None, None

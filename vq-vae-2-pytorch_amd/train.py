@@ -1,0 +1,69 @@
+"""The canonical stage-1 step of /root/reference/train_vqvae.py:83-91 (+166-171, 185-206) as an
+object: forward, MSE + 0.25*latent, backward, ONE packed all-reduce (gradients + the EMA sums of
+both quantizers) over RCCL, deferred EMA update, one-launch Adam, optional CycleScheduler.
+"""
+import torch
+from torch import distributed as dist
+
+from . import distributed as dist_fn
+from . import ops
+from .optim import CycleScheduler, FusedAdam, ParamArena
+
+LATENT_LOSS_WEIGHT = 0.25  # train_vqvae.py:34
+
+
+def stage1_loss(dec, diff, img, latent_loss_weight=LATENT_LOSS_WEIGHT):
+    """(loss, recon_loss, latent_loss) = MSE(dec,img) + w * diff.mean()  (train_vqvae.py:83-85)."""
+    return ops.Stage1LossFn.apply(dec, diff, img, latent_loss_weight)
+
+
+class Stage1Trainer:
+    def __init__(self, model, lr=3e-4, sched=None, n_iter=None, betas=(0.9, 0.999), eps=1e-8):
+        self.model = model
+        live = model.live_parameters() if hasattr(model, "live_parameters") else list(model.parameters())
+        self.quantizers = [m for m in model.modules() if type(m).__name__ == "Quantize"]
+        extra = sum(q.n_embed * (q.dim + 1) for q in self.quantizers)
+        self.arena = ParamArena(live, extra=extra)
+        off = 0
+        for q in self.quantizers:  # EMA statistics ride in the tail of the gradient buffer
+            n = q.n_embed * (q.dim + 1)
+            q.deferred_stats = self.arena.extra[off:off + n]
+            off += n
+        self.optimizer = FusedAdam(live, lr=lr, betas=betas, eps=eps, arena=self.arena)
+        self.scheduler = None
+        if sched == "cycle":  # train_vqvae.py:188-195
+            self.scheduler = CycleScheduler(self.optimizer, lr, n_iter=n_iter, momentum=None, warmup_proportion=0.05)
+        self.world = dist_fn.get_world_size()
+        self.optimizer.grad_scale = 1.0 / self.world  # DDP averages gradients (train_vqvae.py:166-171)
+        self.comm_stream = torch.cuda.Stream() if self.world > 1 else None
+
+    def step(self, img):
+        """One training step on this rank's batch; returns device scalars (no host sync)."""
+        model = self.model
+        model.train()
+        self.arena.zero_grad()
+        self.arena.extra.zero_()
+        dec, diff = model(img)
+        loss, recon, latent = stage1_loss(dec, diff, img)
+        loss.backward()
+        if self.world > 1:
+            if not self.arena.grads_ready():
+                raise RuntimeError("Stage1Trainer: a gradient did not land in the flat arena")
+            # gradients (SUM; Adam divides by world) and EMA sums (SUM, vqvae.py:58-59) in one collective,
+            # issued on a side stream so the host can already enqueue the next step's input work
+            ev = torch.cuda.current_stream().record_event()
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                dist.all_reduce(self.arena.flat_g)
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        for q in self.quantizers:
+            q.apply_deferred_update()
+        if self.scheduler is not None:
+            self.scheduler.step()
+        self.optimizer.step()
+        return {"loss": loss.detach(), "recon": recon, "latent": latent, "dec": dec.detach()}
+
+    def state_dict(self):
+        """Checkpoint in the reference's format (train_vqvae.py:205-206) plus optimizer state."""
+        return {"model": self.model.state_dict(), "adam_m": self.optimizer._m, "adam_v": self.optimizer._v,
+                "adam_t": self.optimizer._t}
