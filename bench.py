@@ -1,0 +1,175 @@
+"""bench.py -- images/sec of the VQ-VAE-2 stage-1 train step (BASELINE.json metric) on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = forward + MSE+0.25*latent loss + backward + EMA codebook update + Adam on one batch of
+synthetic 256x256 images already resident in HBM (BASELINE.json configs[1]: default two-level
+VQVAE, batch 32 per GPU; weak scaling: every rank keeps 32 images, one packed RCCL all-reduce per
+step).  Rank 0 prints ONE JSON line.  The line also carries
+  roofline     -- the dominant kernel (fp32-MFMA implicit-GEMM conv, csrc/vq2_conv.hip): algorithmic
+                  FLOPs of its launches / their HIP-event time, measured live in the timed region
+  cpu_baseline -- the CPU oracle (PyTorch-CPU restatement of the reference graph, kind "port") timed on
+                  this box's host cores on a bounded sample (N=1, rank 0 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
+WORKLOADS = {
+    # name: (image size, per-GPU batch, n_embed, description)
+    "c2": (256, 32, 512, "configs[1]: 256x256 FFHQ-shaped synthetic, default two-level VQ-VAE-2, batch 32/GPU"),
+    "c4": (256, 32, 8192, "configs[3]: 256x256, n_embed=8192 large codebook, batch 32/GPU"),
+    "c5": (512, 8, 512, "configs[4]: 512x512 synthetic, default two-level VQ-VAE-2, batch 8/GPU"),
+    "tiny": (64, 4, 512, "debug: 64x64, batch 4"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--kernel-table", default="", help="write the per-kernel table (JSON) here")
+    return ap.parse_args()
+
+
+def prof_report(lib):
+    import ctypes
+    buf = ctypes.create_string_buffer(1 << 16)
+    rc = lib.vq2_prof_report(buf, len(buf))
+    assert rc == 0, lib.vq2_last_error()
+    rows = {}
+    for line in buf.value.decode().splitlines():
+        name, n, ms, flops, nbytes = line.split()
+        rows[name] = {"launches": int(n), "ms": float(ms), "flops": float(flops), "bytes": float(nbytes)}
+    return rows
+
+
+def cpu_baseline(size, n_embed, budget_s=12.0):
+    """Oracle train step (same graph, same synthetic data) on the host cores."""
+    from oracle import vqvae_oracle as O
+    cfg = O.VQVAEConfig(n_embed=n_embed)
+    st = O.make_state(cfg, 1234)
+    adam = O.AdamState({k: v for k, v in st.items() if not O.is_buffer(k)})
+    b = 8
+    img = O.make_images(b, size, 1234)
+    O.train_step(st, cfg, img, adam)  # warm-up (thread pools, allocator)
+    t0 = time.perf_counter()
+    n = 0
+    while n < 3 or (time.perf_counter() - t0 < budget_s and n < 40):
+        O.train_step(st, cfg, img, adam)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(b * n / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} oracle train steps of batch {b} at {size}x{size} after 1 warm-up "
+                      f"({dt:.1f} s, torch {torch.__version__} CPU kernels)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+
+    import vqvae2_amd
+    from oracle import vqvae_oracle as O
+    lib = vqvae2_amd._lib.lib
+
+    size, batch, n_embed, desc = WORKLOADS[args.workload]
+    if args.batch:
+        batch = args.batch
+    cfg = O.VQVAEConfig(n_embed=n_embed)
+    model = vqvae2_amd.VQVAE(n_embed=n_embed)
+    model.load_state_dict(O.make_state(cfg, 1234))  # identical replicas on every rank
+    model.to(dev)
+    trainer = vqvae2_amd.Stage1Trainer(model, lr=3e-4)
+    img = O.make_images(batch, size, 1234, rank=rank).to(dev)  # resident in HBM before timing
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = trainer.step(img)
+    barrier()
+    if not args.no_prof:
+        lib.vq2_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = trainer.step(img)
+    barrier()
+    dt = time.perf_counter() - t0
+    lib.vq2_prof_enable(0)
+    kernels = prof_report(lib) if not args.no_prof else {}
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss = float(out["loss"])
+    if not (loss == loss):
+        raise SystemExit("loss is NaN")
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = batch * world * args.steps / dt
+        roof = None
+        conv = {k: v for k, v in kernels.items() if k.startswith("conv_gemm")}
+        if conv:
+            dom = max(conv, key=lambda k: conv[k]["ms"])
+            r = conv[dom]
+            ach = r["flops"] / (r["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": r["launches"] // args.steps,
+                    "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2)}
+        line = {
+            "metric": "images/sec VQ-VAE-2 256px train step", "value": round(value, 2), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "global_batch": batch * world, "image": size, "n_embed": n_embed,
+                       "parallelism": f"dp{world}"},
+            "final_loss": round(loss, 6),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(size, n_embed)
+        if kernels:
+            step_ms = {k: round(v["ms"] / args.steps, 4) for k, v in kernels.items()}
+            line["kernel_ms_per_step"] = step_ms
+        if args.kernel_table:
+            with open(args.kernel_table, "w") as f:
+                json.dump(kernels, f, indent=1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -42,6 +42,13 @@ typedef void *vq2_stream_t;
 int vq2_version(void);
 const char *vq2_last_error(void);
 
+/* Measurement aid (bench.py): when enabled, every conv/wgrad/VQ launch is bracketed by two HIP
+ * events on its own stream.  vq2_prof_report waits for them (the ONLY synchronising entry point),
+ * writes one line per kernel "name launches total_ms algorithmic_flops algorithmic_bytes" and
+ * clears the records. */
+int vq2_prof_enable(int on);
+int vq2_prof_report(char *buf, size_t cap);
+
 /* ------------------------------------------------------------------ conv
  * One descriptor describes the FORWARD op; fwd/dgrad/wgrad entry points all
  * take the same descriptor so callers never swap roles by hand.

@@ -27,6 +27,8 @@ def _load():
     sig = {
         "vq2_version": (C.c_int, []),
         "vq2_last_error": (C.c_char_p, []),
+        "vq2_prof_enable": (C.c_int, [C.c_int]),
+        "vq2_prof_report": (C.c_int, [C.c_char_p, SZ]),
         "vq2_pack_weight": (C.c_int, [DP, C.c_int, P, P, P]),
         "vq2_conv_fwd": (C.c_int, [DP, C.c_int, P, P, P, P, I32, P, P]),
         "vq2_conv_dgrad": (C.c_int, [DP, P, P, P, I32, P, I32, P, I32, P]),

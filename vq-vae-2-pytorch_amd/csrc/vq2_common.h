@@ -15,6 +15,17 @@ namespace vq2 {
 int set_error(int code, const char *fmt, ...);
 int check_launch(const char *what);
 
+// optional per-launch event profiling (vq2_prof_enable); see vq2_core.cpp
+bool prof_enabled();
+int prof_begin(const char *name, double flops, double bytes, hipStream_t s);
+void prof_end(int id, hipStream_t s);
+struct ProfScope {
+    int id; hipStream_t s;
+    ProfScope(const char *name, double flops, double bytes, hipStream_t st)
+        : id(prof_enabled() ? prof_begin(name, flops, bytes, st) : -1), s(st) {}
+    ~ProfScope() { if (id >= 0) prof_end(id, s); }
+};
+
 static inline hipStream_t to_stream(vq2_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

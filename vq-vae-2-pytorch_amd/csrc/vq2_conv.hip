@@ -39,6 +39,7 @@ struct ConvGemmParams {
     int ldm, ldr;
     int relu_in, relu_out;
     int nbias;            // bias has nbias entries (real output channels)
+    double flops, bytes;  // algorithmic work of this launch (for the profiler only)
 };
 
 constexpr int BK = 32;        // depth of one staged chunk
@@ -222,6 +223,8 @@ static int launch_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
     auto kern = conv_gemm_kernel<WAVES_M, WAVES_N, MT, NT>;
     allow_big_lds(kern, lds);
     dim3 grid((P.M + BM - 1) / BM, (P.Co + BN - 1) / BN, P.phases);
+    static const char *const name = BN == 128 ? "conv_gemm<128x128>" : (BN == 64 ? "conv_gemm<128x64>" : "conv_gemm<256x32>");
+    ProfScope prof(name, P.flops, P.bytes, s);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, P);
     return check_launch("conv_gemm_kernel");
 }
@@ -337,6 +340,13 @@ extern "C" int vq2_conv_fwd(const vq2_conv_desc *d, int flags, const float *x, c
         P.Ho = d->H; P.Wo = d->W; P.phases = 4;
     }
     P.K = P.KH * P.KW * P.Ci; P.M = P.N * P.Ho * P.Wo;
+    {   // algorithmic work: real channels, every tap once; x read once, y written once (+ residual read)
+        const double cir = d->Cir ? d->Cir : d->Ci, cor = d->Cor ? d->Cor : d->Co;
+        const double pix_in = (double)d->N * d->H * d->W, pix_out = (double)d->N * P.Hy * P.Wy;
+        const double macs = d->transposed ? pix_in * 16.0 * cir * cor : pix_out * d->KH * d->KW * cir * cor;
+        P.flops = 2.0 * macs;
+        P.bytes = 4.0 * (pix_in * cir + pix_out * cor * (residual ? 2.0 : 1.0) + cir * cor * d->KH * d->KW);
+    }
     return run_conv_gemm(P, to_stream(stream));
 }
 
@@ -371,5 +381,13 @@ extern "C" int vq2_conv_dgrad(const vq2_conv_desc *d, const float *dy, const flo
         P.Ho = d->H; P.Wo = d->W; P.phases = 1;
     }
     P.K = P.KH * P.KW * P.Ci; P.M = P.N * P.Ho * P.Wo;
+    {
+        const double cir = d->Cir ? d->Cir : d->Ci, cor = d->Cor ? d->Cor : d->Co;
+        const double pix_in = (double)d->N * d->H * d->W, pix_out = (double)d->N * Hy * Wy;
+        const double macs = d->transposed ? pix_in * 16.0 * cir * cor : pix_out * d->KH * d->KW * cir * cor;
+        P.flops = 2.0 * macs;
+        P.bytes = 4.0 * (pix_out * cor + pix_in * cir * (1.0 + (mask ? 1.0 : 0.0) + (residual ? 1.0 : 0.0)) +
+                         cir * cor * d->KH * d->KW);
+    }
     return run_conv_gemm(P, to_stream(stream));
 }

@@ -262,6 +262,7 @@ extern "C" int vq2_vq_fwd(const float *x, int32_t ldx, const float *embed, const
     VQ2_REQUIRE((counts == nullptr) == (sumsT == nullptr), "vq_fwd: counts and sumsT go together");
     const unsigned grid = (unsigned)((M + VQ_ROWS - 1) / VQ_ROWS);
     hipStream_t s = to_stream(stream);
+    ProfScope prof("vq_fwd", 2.0 * (double)M * D * K, 4.0 * ((double)M * D * 2 + (double)D * K), s);
 #define VQ2_LAUNCH_VQ(DP)                                                                                         \
     hipLaunchKernelGGL(vq_fwd_kernel<DP>, dim3(grid), dim3(256), 0, s, x, ldx, embed, embedT, enorm, M, D, K, idx, \
                        out, ldo, loss_partial, counts, sumsT)

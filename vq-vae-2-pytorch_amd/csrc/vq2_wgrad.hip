@@ -301,6 +301,11 @@ extern "C" int vq2_conv_wgrad(const vq2_conv_desc *d, int flags, const float *x,
                 "conv_wgrad: tensor exceeds 2^31 elements");
     hipStream_t s = to_stream(stream);
     int e;
+    const double cir_ = d->Cir ? d->Cir : d->Ci, cor_ = d->Cor ? d->Cor : d->Co;
+    const double pix_in_ = (double)d->N * d->H * d->W;
+    const double pix_out_ = d->transposed ? 4.0 * pix_in_ : (double)P.M;
+    const double macs_ = d->transposed ? pix_in_ * 16.0 * cir_ * cor_ : pix_out_ * d->KH * d->KW * cir_ * cor_;
+    ProfScope prof("wgrad", 2.0 * macs_, 4.0 * (pix_in_ * cir_ + pix_out_ * cor_ + cir_ * cor_ * d->KH * d->KW), s);
     if (p.bmo == 128) e = launch_wgrad<2, 2, 2, 2>(P, p.S, s);       // 128(o) x 128(k)
     else if (p.bmo == 64) e = launch_wgrad<1, 4, 2, 1>(P, p.S, s);   // 64 x 128
     else e = launch_wgrad<1, 4, 1, 2>(P, p.S, s);                    // 32 x 256
