@@ -139,7 +139,12 @@ def main():
         ms = dt / args.steps * 1e3
         value = batch * world * args.steps / dt
         roof = None
-        conv = {k: v for k, v in kernels.items() if k.startswith("conv_gemm")}
+        fam = {}
+        for k, v in kernels.items():   # fold the per-shape records into kernel families
+            f = fam.setdefault(k.split("|")[0], {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            for kk in f:
+                f[kk] += v[kk]
+        conv = {k: v for k, v in fam.items() if k.startswith("conv_gemm")}
         if conv:
             dom = max(conv, key=lambda k: conv[k]["ms"])
             r = conv[dom]
@@ -160,11 +165,13 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(size, n_embed)
         if kernels:
-            step_ms = {k: round(v["ms"] / args.steps, 4) for k, v in kernels.items()}
-            line["kernel_ms_per_step"] = step_ms
+            line["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 4) for k, v in fam.items()}
         if args.kernel_table:
+            for v in kernels.values():
+                v["tflops"] = round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)
+                v["us_per_launch"] = round(v["ms"] * 1e3 / v["launches"], 1)
             with open(args.kernel_table, "w") as f:
-                json.dump(kernels, f, indent=1)
+                json.dump(dict(sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])), f, indent=1)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

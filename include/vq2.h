@@ -94,13 +94,14 @@ int vq2_conv_fwd(const vq2_conv_desc *d, int flags, const float *x, const float 
 int vq2_conv_dgrad(const vq2_conv_desc *d, const float *dy, const float *wp, const float *mask, int32_t ldmask,
                    const float *residual, int32_t ldres, float *dx, int32_t lddx, vq2_stream_t stream);
 
-/* dw (reference layout, OIHW or IOHW) = wgrad([relu]x, dy); deterministic
- * split-K: partial slabs in `ws`, then an ordered reduction. flags: VQ2_RELU_IN. */
+/* dw (reference layout, OIHW or IOHW) = wgrad([relu]x, dy) and, if db != NULL, db[Cor] = sum over
+ * pixels of dy (bias gradient, fused).  Deterministic split-K: partial slabs in `ws`, then an
+ * ordered reduction.  flags: VQ2_RELU_IN. */
 size_t vq2_conv_wgrad_workspace_bytes(const vq2_conv_desc *d);
-int vq2_conv_wgrad(const vq2_conv_desc *d, int flags, const float *x, const float *dy, float *dw, void *ws,
+int vq2_conv_wgrad(const vq2_conv_desc *d, int flags, const float *x, const float *dy, float *dw, float *db, void *ws,
                    size_t ws_bytes, vq2_stream_t stream);
 
-/* db[c] = sum over pixels of dy[.,c]  (bias gradient).  ws: >= vq2_colsum_workspace_bytes. */
+/* out[c] = sum over rows of x[.,c] (stand-alone column sums).  ws: >= vq2_colsum_workspace_bytes. */
 size_t vq2_colsum_workspace_bytes(int64_t rows, int32_t C);
 int vq2_colsum(const float *dy, int64_t rows, int32_t C, int32_t ld, float *db, void *ws, size_t ws_bytes,
                vq2_stream_t stream);

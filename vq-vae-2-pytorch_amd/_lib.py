@@ -33,7 +33,7 @@ def _load():
         "vq2_conv_fwd": (C.c_int, [DP, C.c_int, P, P, P, P, I32, P, P]),
         "vq2_conv_dgrad": (C.c_int, [DP, P, P, P, I32, P, I32, P, I32, P]),
         "vq2_conv_wgrad_workspace_bytes": (SZ, [DP]),
-        "vq2_conv_wgrad": (C.c_int, [DP, C.c_int, P, P, P, P, SZ, P]),
+        "vq2_conv_wgrad": (C.c_int, [DP, C.c_int, P, P, P, P, P, SZ, P]),
         "vq2_colsum_workspace_bytes": (SZ, [I64, I32]),
         "vq2_colsum": (C.c_int, [P, I64, I32, I32, P, P, SZ, P]),
         "vq2_nchw_to_nhwc": (C.c_int, [P, P, I32, I32, I32, I32, I32, P]),

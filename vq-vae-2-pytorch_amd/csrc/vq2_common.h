@@ -17,6 +17,7 @@ int check_launch(const char *what);
 
 // optional per-launch event profiling (vq2_prof_enable); see vq2_core.cpp
 bool prof_enabled();
+const char *prof_label(const char *fmt, ...);
 int prof_begin(const char *name, double flops, double bytes, hipStream_t s);
 void prof_end(int id, hipStream_t s);
 struct ProfScope {

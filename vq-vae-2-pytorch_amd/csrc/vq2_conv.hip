@@ -223,7 +223,9 @@ static int launch_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
     auto kern = conv_gemm_kernel<WAVES_M, WAVES_N, MT, NT>;
     allow_big_lds(kern, lds);
     dim3 grid((P.M + BM - 1) / BM, (P.Co + BN - 1) / BN, P.phases);
-    static const char *const name = BN == 128 ? "conv_gemm<128x128>" : (BN == 64 ? "conv_gemm<128x64>" : "conv_gemm<256x32>");
+    const char *name = "conv_gemm";
+    if (prof_enabled())
+        name = prof_label("conv_gemm<%dx%d>|M=%d,N=%d,K=%d,k%d,s%d,ph%d", BM, BN, P.M, P.Co, P.K, P.KH, P.stride, P.phases);
     ProfScope prof(name, P.flops, P.bytes, s);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, P);
     return check_launch("conv_gemm_kernel");

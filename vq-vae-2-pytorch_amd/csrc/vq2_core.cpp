@@ -35,6 +35,20 @@ static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_free;
 
 bool prof_enabled() { return g_prof_on.load(std::memory_order_relaxed) != 0; }
 
+// intern a formatted kernel+shape label (pointers stay valid for the life of the process)
+const char *prof_label(const char *fmt, ...) {
+    char tmp[160];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(tmp, sizeof(tmp), fmt, ap);
+    va_end(ap);
+    static std::vector<char *> pool;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (char *p : pool) if (strcmp(p, tmp) == 0) return p;
+    pool.push_back(strdup(tmp));
+    return pool.back();
+}
+
 int prof_begin(const char *name, double flops, double bytes, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfRec r{name, nullptr, nullptr, flops, bytes};

@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void vq_fwd_kernel(const float *__restrict__ x
     __shared__ __attribute__((aligned(16))) float Es[DP * VQ_CT];
     __shared__ float En[VQ_CT];
     __shared__ float wsum[4];
+    __shared__ int slead[VQ_ROWS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, h = lane >> 5;
@@ -115,27 +116,72 @@ __global__ __launch_bounds__(256) void vq_fwd_kernel(const float *__restrict__ x
     __syncthreads();
     if (tid == 0 && loss_partial) loss_partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 
-    // EMA statistics (vqvae.py:55-56): one 4*D-byte contiguous atomic burst per latent vector
-    if (counts && sumsT) {
-        if (rv && h == 0) atomicAdd(counts + besti, 1.0f);
+    // EMA statistics (vqvae.py:55-56): sumsT[code][:] += x rows.  Early in training (and on synthetic
+    // data) most vectors pick the same few codes, and same-address float atomics serialise at the
+    // memory side (~25 ns each), so equal codes are merged on chip first: per wave in registers, then
+    // per workgroup in LDS (the staging buffer is free now); one 4*D-byte atomic burst per distinct
+    // code leaves the workgroup.
+    if (sumsT) {
+        __syncthreads();                                 // every wave is done with Es / En
+        float *ssum = Es;                                // [128 slots][DP]
+        int *scode = reinterpret_cast<int *>(En);        // [128] code of a slot, -1 = unused
         const int64_t wrow0 = (int64_t)blockIdx.x * VQ_ROWS + wave * 32;
-        if (D >= 64) {
-            for (int r = 0; r < 32; ++r) {
-                const int64_t rr = wrow0 + r;
-                if (rr >= M) break;
-                const int code = __shfl(besti, r, 64);
-                for (int d = lane; d < D; d += 64) atomicAdd(sumsT + (size_t)code * D + d, x[rr * ldx + d]);
+        unsigned long long rem = __ballot(rv && h == 0);
+        int nslots = 0;
+        while (rem) {
+            const int leader = __ffsll((long long)rem) - 1;
+            const int code = __shfl(besti, leader, 64);
+            const unsigned long long same = __ballot(rv && h == 0 && besti == code);
+            float v = 0.f;
+            unsigned long long it = same;
+            while (it) {
+                const int r = __ffsll((long long)it) - 1;
+                it &= it - 1;
+                if (lane < D) v += x[(wrow0 + r) * ldx + lane];
             }
-        } else {
-            const int rpi = 64 / D;  // rows per wave-instruction (D in {4,8,16,32})
-            const int rs = lane / D, d = lane % D;
-            for (int r = 0; r < 32; r += rpi) {
-                const int64_t rr = wrow0 + r + rs;
-                const int code = __shfl(besti, (r + rs) & 31, 64);
-                if (rs < rpi && rr < M) atomicAdd(sumsT + (size_t)code * D + d, x[rr * ldx + d]);
-            }
+            const int slot = wave * 32 + nslots;
+            if (lane < D) ssum[slot * DP + lane] = v;
+            if (lane == 0) scode[slot] = code;
+            ++nslots;
+            rem &= ~same;
+        }
+        if (lane >= nslots && lane < 32) scode[wave * 32 + lane] = -1;
+        __syncthreads();
+        if (tid < VQ_ROWS) {                             // leader of a code = its first slot in the workgroup
+            const int myc = scode[tid];
+            int lead = tid;
+            if (myc >= 0)
+                for (int q = 0; q < tid; ++q)
+                    if (scode[q] == myc) { lead = q; break; }
+            slead[tid] = lead;
+        }
+        __syncthreads();
+        for (int sl = wave; sl < VQ_ROWS; sl += 4) {     // fold followers into their leader (LDS atomics)
+            const int l = slead[sl];
+            if (scode[sl] >= 0 && l != sl && lane < D) atomicAdd(&ssum[l * DP + lane], ssum[sl * DP + lane]);
+        }
+        __syncthreads();
+        for (int sl = wave; sl < VQ_ROWS; sl += 4) {
+            const int c = scode[sl];
+            if (c >= 0 && slead[sl] == sl && lane < D) atomicAdd(sumsT + (size_t)c * D + lane, ssum[sl * DP + lane]);
         }
     }
+}
+
+// counts[k] += #{m : idx[m] == k}: LDS-privatised histogram, then one contiguous burst of atomics per
+// workgroup (integers are exact in fp32 up to 2^24, so the result does not depend on the order)
+__global__ __launch_bounds__(256) void vq_hist_kernel(const int64_t *__restrict__ idx, int64_t M, int K,
+                                                      float *__restrict__ counts) {
+    extern __shared__ int hist[];
+    for (int k = threadIdx.x; k < K; k += 256) hist[k] = 0;
+    __syncthreads();
+    for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
+        const int c = (int)idx[m];
+        if ((unsigned)c < (unsigned)K) atomicAdd(&hist[c], 1);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += 256)
+        if (hist[k]) atomicAdd(counts + k, (float)hist[k]);
 }
 
 __global__ void vq_prepare_kernel(const float *__restrict__ embed, float *__restrict__ embedT,
@@ -270,7 +316,15 @@ extern "C" int vq2_vq_fwd(const float *x, int32_t ldx, const float *embed, const
     else if (D <= 32) VQ2_LAUNCH_VQ(32);
     else VQ2_LAUNCH_VQ(64);
 #undef VQ2_LAUNCH_VQ
-    return check_launch("vq_fwd_kernel");
+    if (int e = check_launch("vq_fwd_kernel")) return e;
+    if (counts) {
+        VQ2_REQUIRE(K <= 16384, "vq_fwd: n_embed > 16384 not supported by the histogram kernel");
+        const int hb = (int)((M + 256 * 64 - 1) / (256 * 64));  // >= 64 indices per thread
+        hipLaunchKernelGGL(vq_hist_kernel, dim3(hb < 1 ? 1 : (hb > 128 ? 128 : hb)), dim3(256), (size_t)K * sizeof(int), s,
+                           idx, M, K, counts);
+        return check_launch("vq_hist_kernel");
+    }
+    return VQ2_OK;
 }
 
 extern "C" int vq2_vq_loss(const float *loss_partial, int64_t M, int32_t D, float *diff, vq2_stream_t stream) {

@@ -20,6 +20,7 @@ struct WgradParams {
     const float *x;  // image operand [N,H,W,ldx], I channels
     const float *g;  // grad  operand [N,Ho,Wo,ldg], O channels
     float *ws;       // [S][O][K] partial slabs
+    float *bias_ws;  // [S][O] partial column sums of g (bias gradient) or null
     int N, H, W, I, ldx;
     int Ho, Wo, O, ldg;
     int KH, KW, stride, pad;
@@ -119,9 +120,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
     }
     __syncthreads();
     const int fr = lane & 31, fk = lane >> 5;
+    const bool do_bias = P.bias_ws != nullptr && blockIdx.x == 0 && tid < BMO;
+    float bsum = 0.f;
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunks) load_chunk(m_begin + (c + 1) * WG_BKR);
+        if (do_bias) {  // bias gradient rides along: column sums of the staged grad tile
+            const float *gcol = Gs + buf * WG_BKR * BMO + tid;
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < WG_BKR; r += 2) { s0 += gcol[r * BMO]; s1 += gcol[(r + 1) * BMO]; }
+            bsum += s0 + s1;
+        }
         const float *gs = Gs + buf * WG_BKR * BMO + fk * BMO + wm * MT * 32 + fr;
         const float *xs = Xs + buf * WG_BKR * BNK + fk * BNK + wn * NT * 32 + fr;
 #pragma unroll
@@ -140,6 +150,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
         if (c + 1 < nchunks) store_chunk(buf ^ 1);
         __syncthreads();
     }
+
+    if (do_bias && o0 + tid < P.O) P.bias_ws[(size_t)split * P.O + o0 + tid] = bsum;
 
     // partial tile -> slab [split][o][k]
     float *slab = P.ws + (size_t)split * P.O * P.K;
@@ -160,20 +172,37 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
     }
 }
 
-// sum slabs in split order; scatter [o][tap][i] (padded O x I) -> reference layout [Or][Ir][tap]
+// sum slabs in split order; scatter [o][tap][i] (padded O x I) -> reference layout [Or][Ir][tap];
+// the last block also folds the bias partials
 __global__ void wgrad_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, int O, int I, int Or, int Ir,
-                                    int taps, int S) {
+                                    int taps, int S, const float *__restrict__ bias_ws, float *__restrict__ db) {
     const int K = taps * I;
     const int total = O * K;
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
         const int o = t / K, k = t - o * K;
         const int tap = k / I, i = k - tap * I;
         if (o >= Or || i >= Ir) continue;
-        float s = 0.f;
-        for (int z = 0; z < S; ++z) s += ws[(size_t)z * total + t];
-        dw[((size_t)o * Ir + i) * taps + tap] = s;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int z = 0;
+        for (; z + 4 <= S; z += 4) {
+            s0 += ws[(size_t)z * total + t];
+            s1 += ws[(size_t)(z + 1) * total + t];
+            s2 += ws[(size_t)(z + 2) * total + t];
+            s3 += ws[(size_t)(z + 3) * total + t];
+        }
+        for (; z < S; ++z) s0 += ws[(size_t)z * total + t];
+        dw[((size_t)o * Ir + i) * taps + tap] = (s0 + s1) + (s2 + s3);
+    }
+    if (db && bias_ws && blockIdx.x == gridDim.x - 1) {
+        for (int o = threadIdx.x; o < Or; o += blockDim.x) {
+            float s = 0.f;
+            for (int z = 0; z < S; ++z) s += bias_ws[(size_t)z * O + o];
+            db[o] = s;
+        }
     }
 }
+
+static int colsum_impl(const float *dy, int64_t rows, int C, int ld, float *db, int nout, float *ws, hipStream_t s);
 
 struct WgradPlan {
     int O, I, K, M, S, rows_per_split, bmo;
@@ -193,7 +222,7 @@ static WgradPlan plan_wgrad(const vq2_conv_desc *d) {
     p.bmo = p.O > 64 ? 128 : (p.O > 32 ? 64 : 32);
     const int bnk = p.bmo == 32 ? 256 : 128;
     const int tiles = ((p.K + bnk - 1) / bnk) * ((p.O + p.bmo - 1) / p.bmo);
-    int S = (1024 + tiles - 1) / tiles;              // aim at >= 4 workgroups per CU
+    int S = (512 + tiles - 1) / tiles;               // aim at ~2 workgroups per CU (slab traffic grows with S)
     const int max_s = (p.M + 255) / 256;             // at least 8 chunks of 32 rows per split
     if (S > max_s) S = max_s;
     if (S > 512) S = 512;
@@ -217,15 +246,20 @@ static int launch_wgrad(const WgradParams &P, int S, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------ column sums (bias gradient)
-constexpr int CS_ROWS_PER_BLOCK = 2048;
+constexpr int CS_MAX_BLOCKS = 512;
+
+static inline int64_t cs_rows_per_block(int64_t rows) {
+    int64_t rpb = (rows + CS_MAX_BLOCKS - 1) / CS_MAX_BLOCKS;
+    return rpb < 256 ? 256 : rpb;
+}
 
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ x, int64_t rows, int C, int ld,
-                                                             float *__restrict__ part) {
+                                                             int64_t rpb, float *__restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float red[];  // [nrg][C]
     const int C4 = C / 4;
     const int nrg = 256 / C4 > 0 ? 256 / C4 : 1;
-    const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS_PER_BLOCK;
-    const int64_t r1 = r0 + CS_ROWS_PER_BLOCK < rows ? r0 + CS_ROWS_PER_BLOCK : rows;
+    const int64_t r0 = (int64_t)blockIdx.x * rpb;
+    const int64_t r1 = r0 + rpb < rows ? r0 + rpb : rows;
     for (int cbase = 0; cbase < C4; cbase += 256) {
         const int c4 = cbase + (int)(threadIdx.x % (C4 < 256 ? C4 : 256));
         const int rg = threadIdx.x / (C4 < 256 ? C4 : 256);
@@ -249,12 +283,25 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__rest
     }
 }
 
-__global__ void colsum_final_kernel(const float *__restrict__ part, int nblocks, int C, float *__restrict__ out) {
+__global__ void colsum_final_kernel(const float *__restrict__ part, int nblocks, int C, int nout,
+                                    float *__restrict__ out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    if (c >= nout) return;
     float s = 0.f;
     for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * C + c];
     out[c] = s;
+}
+
+static int colsum_impl(const float *dy, int64_t rows, int C, int ld, float *db, int nout, float *ws, hipStream_t s) {
+    const int64_t rpb = cs_rows_per_block(rows);
+    const int64_t nb = (rows + rpb - 1) / rpb;
+    const int C4 = C / 4;
+    const int nrg = 256 / C4 > 0 ? 256 / C4 : 1;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nb), dim3(256), (size_t)nrg * C * sizeof(float), s, dy, rows,
+                       C, ld, rpb, ws);
+    if (int e = check_launch("colsum_partial_kernel")) return e;
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((nout + 255) / 256), dim3(256), 0, s, ws, (int)nb, C, nout, db);
+    return check_launch("colsum_final_kernel");
 }
 
 }  // namespace vq2
@@ -264,11 +311,11 @@ using namespace vq2;
 extern "C" size_t vq2_conv_wgrad_workspace_bytes(const vq2_conv_desc *d) {
     if (!d || d->N <= 0 || d->Ci <= 0 || d->Co <= 0) return 0;
     const WgradPlan p = plan_wgrad(d);
-    return (size_t)p.S * p.O * p.K * sizeof(float);
+    return (size_t)p.S * p.O * (p.K + 1) * sizeof(float) + vq2_colsum_workspace_bytes((int64_t)d->N * 4 * d->H * d->W, d->Co);
 }
 
-extern "C" int vq2_conv_wgrad(const vq2_conv_desc *d, int flags, const float *x, const float *dy, float *dw, void *ws,
-                              size_t ws_bytes, vq2_stream_t stream) {
+extern "C" int vq2_conv_wgrad(const vq2_conv_desc *d, int flags, const float *x, const float *dy, float *dw, float *db,
+                              void *ws, size_t ws_bytes, vq2_stream_t stream) {
     VQ2_REQUIRE(d && x && dy && dw && ws, "conv_wgrad: null pointer");
     VQ2_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Ci > 0 && d->Co > 0 && d->Ci % 4 == 0 && d->Co % 4 == 0,
                 "conv_wgrad: bad dims");
@@ -280,9 +327,12 @@ extern "C" int vq2_conv_wgrad(const vq2_conv_desc *d, int flags, const float *x,
         VQ2_REQUIRE(d->KH == d->KW && d->KH >= 1 && d->KH <= 7 && (d->stride == 1 || d->stride == 2) && d->pad >= 0,
                     "conv_wgrad: unsupported conv geometry");
     const WgradPlan p = plan_wgrad(d);
-    VQ2_REQUIRE(ws_bytes >= (size_t)p.S * p.O * p.K * sizeof(float), "conv_wgrad: workspace too small");
+    VQ2_REQUIRE(ws_bytes >= vq2_conv_wgrad_workspace_bytes(d), "conv_wgrad: workspace too small");
     WgradParams P{};
     P.ws = static_cast<float *>(ws);
+    float *bias_ws = P.ws + (size_t)p.S * p.O * p.K;       // [S][O] bias partials (conv only)
+    float *colsum_ws = bias_ws + (size_t)p.S * p.O;        // convT: separate column-sum pass over dy
+    P.bias_ws = (db && !d->transposed) ? bias_ws : nullptr;
     P.KH = d->KH; P.KW = d->KW; P.stride = d->stride; P.pad = d->pad;
     P.O = p.O; P.I = p.I; P.K = p.K; P.M = p.M; P.rows_per_split = p.rows_per_split;
     P.N = d->N;
@@ -305,7 +355,9 @@ extern "C" int vq2_conv_wgrad(const vq2_conv_desc *d, int flags, const float *x,
     const double pix_in_ = (double)d->N * d->H * d->W;
     const double pix_out_ = d->transposed ? 4.0 * pix_in_ : (double)P.M;
     const double macs_ = d->transposed ? pix_in_ * 16.0 * cir_ * cor_ : pix_out_ * d->KH * d->KW * cir_ * cor_;
-    ProfScope prof("wgrad", 2.0 * macs_, 4.0 * (pix_in_ * cir_ + pix_out_ * cor_ + cir_ * cor_ * d->KH * d->KW), s);
+    const char *pname = "wgrad";
+    if (prof_enabled()) pname = prof_label("wgrad<%d>|O=%d,K=%d,M=%d,S=%d,k%d", p.bmo, p.O, p.K, p.M, p.S, d->KH);
+    ProfScope prof(pname, 2.0 * macs_, 4.0 * (pix_in_ * cir_ + pix_out_ * cor_ + cir_ * cor_ * d->KH * d->KW), s);
     if (p.bmo == 128) e = launch_wgrad<2, 2, 2, 2>(P, p.S, s);       // 128(o) x 128(k)
     else if (p.bmo == 64) e = launch_wgrad<1, 4, 2, 1>(P, p.S, s);   // 64 x 128
     else e = launch_wgrad<1, 4, 1, 2>(P, p.S, s);                    // 32 x 256
@@ -315,14 +367,19 @@ extern "C" int vq2_conv_wgrad(const vq2_conv_desc *d, int flags, const float *x,
     const int cir = d->Cir ? d->Cir : d->Ci, cor = d->Cor ? d->Cor : d->Co;
     const int Or = d->transposed ? cir : cor, Ir = d->transposed ? cor : cir;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, P.ws, dw, p.O, p.I, Or, Ir, d->KH * d->KW,
-                       p.S);
-    return check_launch("wgrad_reduce_kernel");
+                       p.S, P.bias_ws, db);
+    if (int e2 = check_launch("wgrad_reduce_kernel")) return e2;
+    if (db && d->transposed) {  // bias gradient of a conv-transpose = column sums of dy [N,2H,2W,Co]
+        const int64_t rows = (int64_t)d->N * 4 * d->H * d->W;
+        return colsum_impl(dy, rows, d->Co, d->ldy, db, cor, colsum_ws, s);
+    }
+    return VQ2_OK;
 }
 
 extern "C" size_t vq2_colsum_workspace_bytes(int64_t rows, int32_t C) {
     if (rows <= 0 || C <= 0) return 0;
-    const int64_t nb = (rows + CS_ROWS_PER_BLOCK - 1) / CS_ROWS_PER_BLOCK;
-    return (size_t)nb * C * sizeof(float);
+    const int64_t rpb = cs_rows_per_block(rows);
+    return (size_t)((rows + rpb - 1) / rpb) * C * sizeof(float);
 }
 
 extern "C" int vq2_colsum(const float *dy, int64_t rows, int32_t C, int32_t ld, float *db, void *ws, size_t ws_bytes,
@@ -330,15 +387,6 @@ extern "C" int vq2_colsum(const float *dy, int64_t rows, int32_t C, int32_t ld, 
     VQ2_REQUIRE(dy && db && ws, "colsum: null pointer");
     VQ2_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && ld >= C && ld % 4 == 0 && C <= 4096, "colsum: bad shape");
     VQ2_REQUIRE(aligned16(dy), "colsum: dy must be 16-byte aligned");
-    const int64_t nb = (rows + CS_ROWS_PER_BLOCK - 1) / CS_ROWS_PER_BLOCK;
-    VQ2_REQUIRE(ws_bytes >= (size_t)nb * C * sizeof(float), "colsum: workspace too small");
-    const int C4 = C / 4;
-    const int nrg = 256 / C4 > 0 ? 256 / C4 : 1;
-    hipStream_t s = to_stream(stream);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nb), dim3(256), (size_t)nrg * C * sizeof(float), s, dy, rows,
-                       C, ld, static_cast<float *>(ws));
-    if (int e = check_launch("colsum_partial_kernel")) return e;
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s, static_cast<const float *>(ws),
-                       (int)nb, C, db);
-    return check_launch("colsum_final_kernel");
+    VQ2_REQUIRE(ws_bytes >= vq2_colsum_workspace_bytes(rows, C), "colsum: workspace too small");
+    return colsum_impl(dy, rows, C, ld, db, C, static_cast<float *>(ws), to_stream(stream));
 }

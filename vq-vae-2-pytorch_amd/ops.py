@@ -172,36 +172,25 @@ def conv_dgrad(spec, xshape, dy, weight, mask=None, residual=None, out=None):
     return out
 
 
-def conv_wgrad(spec, x, dy, relu_in, weight_like):
+def _grad_slot(param):
+    """ParamArena: the gradient of `param` lands directly in the flat gradient buffer."""
+    slot = getattr(param, "_vq2_grad", None) if param is not None else None
+    if slot is not None:
+        return slot.view_as(slot)  # fresh tensor object so autograd can adopt it as .grad without a copy
+    return None if param is None else torch.empty_like(param, memory_format=torch.contiguous_format)
+
+
+def conv_wgrad(spec, x, dy, relu_in, weight, bias=None, want_dw=True, want_db=True):
+    """(dw, db) in the reference layouts; the bias gradient is fused into the same launches."""
     n, h, w, _ = x.shape
     d = _desc(spec, n, h, w, ld_of(x), ld_of(dy))
     nbytes = lib.vq2_conv_wgrad_workspace_bytes(C.byref(d))
     ws = torch.empty(max(nbytes // 4, 4), device=x.device, dtype=torch.float32)
-    slot = getattr(weight_like, "_vq2_grad", None)  # ParamArena: gradient lands in the flat buffer
-    dw = slot.view_as(slot) if slot is not None else torch.empty_like(weight_like,
-                                                                      memory_format=torch.contiguous_format)
-    check(lib.vq2_conv_wgrad(C.byref(d), VQ2_RELU_IN if relu_in else 0, _p(x), _p(dy), _p(dw), _p(ws), nbytes,
+    dw = _grad_slot(weight)
+    db = _grad_slot(bias) if (bias is not None and want_db) else None
+    check(lib.vq2_conv_wgrad(C.byref(d), VQ2_RELU_IN if relu_in else 0, _p(x), _p(dy), _p(dw), _p(db), _p(ws), nbytes,
                              _stream()), "conv_wgrad")
-    return dw
-
-
-def bias_grad(dy, cout, bias_like=None):
-    n, h, w, c = dy.shape
-    rows = n * h * w
-    nbytes = lib.vq2_colsum_workspace_bytes(rows, c)
-    ws = torch.empty(max(nbytes // 4, 4), device=dy.device, dtype=torch.float32)
-    slot = getattr(bias_like, "_vq2_grad", None) if bias_like is not None else None
-    if slot is not None and cout == c:
-        db = slot.view_as(slot)
-    else:
-        db = torch.empty(c, device=dy.device, dtype=torch.float32)
-    check(lib.vq2_colsum(_p(dy), rows, c, ld_of(dy), _p(db), _p(ws), nbytes, _stream()), "colsum")
-    if cout != c:
-        db = db[:cout]
-        if slot is not None:  # padded 3-channel case: copy the real entries into the arena slot
-            check(lib.vq2_axpby(_p(db), _p(db), 0.0, _p(slot), cout, _stream()), "axpby")
-            db = slot.view_as(slot)
-    return db
+    return (dw if want_dw else None), db
 
 
 def relu_bwd(dy, y):
@@ -328,10 +317,9 @@ class ConvFn(Function):
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
             dx = conv_dgrad(spec, x.shape, g, weight, mask=x if relu_in else None)
-        if ctx.needs_input_grad[1]:
-            dw = conv_wgrad(spec, x, g, relu_in, weight)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = bias_grad(g, spec.cout, bias)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = conv_wgrad(spec, x, g, relu_in, weight, bias, ctx.needs_input_grad[1],
+                                ctx.has_bias and ctx.needs_input_grad[2])
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = g
         return dx, dw, db, dres, None, None, None
@@ -368,12 +356,10 @@ class ResBlockFn(Function):
             g = relu_bwd(g, y)
         # through conv1x1 and the inner ReLU (mask r > 0)
         dh = conv_dgrad(s2, r.shape, g, w2, mask=r)
-        dw2 = conv_wgrad(s2, r, g, False, w2) if ctx.needs_input_grad[3] else None
-        db2 = bias_grad(g, s2.cout, b2) if ctx.needs_input_grad[4] else None
+        dw2, db2 = conv_wgrad(s2, r, g, False, w2, b2, ctx.needs_input_grad[3], ctx.needs_input_grad[4])
         # through conv3x3 and the outer ReLU (mask x > 0), plus the skip gradient
         dx = conv_dgrad(s1, x.shape, dh, w1, mask=x, residual=g) if ctx.needs_input_grad[0] else None
-        dw1 = conv_wgrad(s1, x, dh, True, w1) if ctx.needs_input_grad[1] else None
-        db1 = bias_grad(dh, s1.cout, b1) if ctx.needs_input_grad[2] else None
+        dw1, db1 = conv_wgrad(s1, x, dh, True, w1, b1, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         return dx, dw1, db1, dw2, db2, None, None, None, None
 
 
