@@ -36,6 +36,16 @@ __device__ __forceinline__ float4 relu4(float4 v) {
     return v;
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (each with a private L2): linear id L runs on XCD
+// L % 8.  Remap so that every XCD works on one CONTIGUOUS range of virtual ids -- neighbouring tiles
+// (shared halo rows, shared operand panels) then hit the same L2.  Bijective for any total; only a
+// speed choice, never correctness (MI355X_MICROARCH.md, workgroup dispatch).
+__device__ __forceinline__ int xcd_remap(int L, int total) {
+    const int q = total >> 3, r = total & 7;
+    const int xcd = L & 7, slot = L >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

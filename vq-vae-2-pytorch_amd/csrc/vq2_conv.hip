@@ -20,6 +20,7 @@
 // ConvTranspose2d(k4,s2,p1) and the data-gradient of a stride-2 4x4 conv are the same
 // sub-pixel decomposition: 4 output phases, each a 2x2 stride-1 conv; blockIdx.z = phase.
 #include "vq2_common.h"
+#include <stdlib.h>
 
 namespace vq2 {
 
@@ -42,15 +43,18 @@ struct ConvGemmParams {
     double flops, bytes;  // algorithmic work of this launch (for the profiler only)
 };
 
-constexpr int BK = 32;        // depth of one staged chunk
-constexpr int LDK = BK + 4;   // padded LDS row: 144 B -> ds_read_b128 conflict-free
-
-template <int WAVES_M, int WAVES_N, int MT, int NT>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams P) {
+// BK = depth of one staged chunk; LDS rows are padded to BK+4 floats (144 B / 80 B), which makes the
+// ds_read_b128 fragment reads conflict-free (16-byte slot index = row*9 resp. row*5 mod 16).
+template <int WAVES_M, int WAVES_N, int MT, int NT, int BK>
+__global__ __launch_bounds__(256, (BK == 16 && MT * NT == 4) ? 3 : 1) void conv_gemm_kernel(const ConvGemmParams P) {
+    constexpr int LDK = BK + 4;
     constexpr int BM = WAVES_M * MT * 32;
     constexpr int BN = WAVES_N * NT * 32;
-    constexpr int A_LD = BM / 32;  // float4 loads per thread per chunk (A)
-    constexpr int B_LD = BN / 32;
+    constexpr int KQ = BK / 4;            // float4 per staged row
+    constexpr int RPP = 256 / KQ;         // rows staged per pass of the 256 threads
+    constexpr int A_LD = BM / RPP;        // float4 loads per thread per chunk (A)
+    constexpr int B_LD = (BN + RPP - 1) / RPP;  // BN < RPP: only the first BN staging rows carry weights
+    static_assert(BM % RPP == 0 && (BN % RPP == 0 || BN < RPP), "tile vs staging shape");
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                  // [2][BM][LDK]
@@ -61,25 +65,30 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams P) 
     const int wave = tid >> 6;
     const int wm = wave / WAVES_N;
     const int wn = wave % WAVES_N;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // 1-D grid, XCD-aware: virtual id -> (n-tile fastest, then m-tile, then phase)
+    const int ntiles = (P.Co + BN - 1) / BN;
+    const int mtiles = (P.M + BM - 1) / BM;
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = (vid % ntiles) * BN;
+    const int m0 = ((vid / ntiles) % mtiles) * BM;
+    const int phase = vid / (ntiles * mtiles);
 
     int pad_h = P.pad_h, pad_w = P.pad_w, oh = 0, ow = 0, os = 1;
     const float *wp = P.w;
     if (P.phases == 4) {
-        const int ph = blockIdx.z >> 1, pw = blockIdx.z & 1;
+        const int ph = phase >> 1, pw = phase & 1;
         pad_h = 1 - ph; pad_w = 1 - pw; oh = ph; ow = pw; os = 2;
-        wp += (size_t)blockIdx.z * P.Co * P.K;
+        wp += (size_t)phase * P.Co * P.K;
     }
 
     // ---- per-thread staging coordinates (fixed over the K loop)
-    const int lrow = tid >> 3;        // 0..31
-    const int lk = (tid & 7) * 4;     // float4 column inside a chunk
+    const int lrow = tid / KQ;        // 0..RPP-1
+    const int lk = (tid % KQ) * 4;    // float4 column inside a chunk
     int a_pix[A_LD], a_h[A_LD], a_w[A_LD];
     const int HoWo = P.Ho * P.Wo;
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
-        const int m = m0 + lrow + 32 * j;
+        const int m = m0 + lrow + RPP * j;
         if (m < P.M) {
             const int n = m / HoWo;
             const int r = m - n * HoWo;
@@ -110,13 +119,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams P) 
             const bool v = kv && (unsigned)(a_h[j] + kh) < (unsigned)P.H && (unsigned)(a_w[j] + kw) < (unsigned)P.W;
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
             if (v) val = *reinterpret_cast<const float4 *>(P.x + (size_t)(a_pix[j] + kh * P.W + kw) * P.ldx + ci);
-            ra[j] = P.relu_in ? relu4(val) : val;
+            ra[j] = val;  // ReLU is applied when the registers are written to LDS (no wait on the load here)
         }
 #pragma unroll
         for (int j = 0; j < B_LD; ++j) {
-            const int co = n0 + lrow + 32 * j;
+            const int co = n0 + lrow + RPP * j;
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kv && co < P.Co) val = *reinterpret_cast<const float4 *>(wp + (size_t)co * P.K + kglob);
+            if (kv && co < P.Co && lrow + RPP * j < BN) val = *reinterpret_cast<const float4 *>(wp + (size_t)co * P.K + kglob);
             rb[j] = val;
         }
     };
@@ -132,9 +141,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams P) 
         float *a = As + buf * BM * LDK;
         float *b = Bs + buf * BN * LDK;
 #pragma unroll
-        for (int j = 0; j < A_LD; ++j) *reinterpret_cast<float4 *>(a + (lrow + 32 * j) * LDK + lk) = ra[j];
+        for (int j = 0; j < A_LD; ++j)
+            *reinterpret_cast<float4 *>(a + (lrow + RPP * j) * LDK + lk) = P.relu_in ? relu4(ra[j]) : ra[j];
 #pragma unroll
-        for (int j = 0; j < B_LD; ++j) *reinterpret_cast<float4 *>(b + (lrow + 32 * j) * LDK + lk) = rb[j];
+        for (int j = 0; j < B_LD; ++j)
+            if (BN % RPP == 0 || lrow + RPP * j < BN) *reinterpret_cast<float4 *>(b + (lrow + RPP * j) * LDK + lk) = rb[j];
     };
 
     f32x16 acc[MT][NT];
@@ -181,7 +192,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams P) 
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds column (lane&31) of 16 rows per 32x32 tile
+    // ---- epilogue: lane holds column (lane&31) of 16 rows per 32x32 tile.
+    // All mask/residual loads of a tile are issued BEFORE its stores: y may alias neither, but the
+    // compiler cannot know that, and a load->store->load chain would serialise on HBM latency.
+    const float *__restrict__ maskp = P.mask;
+    const float *__restrict__ resp = P.res;
+    float *__restrict__ yp = P.y;
     const int colq = lane & 31;
     const int rowq = 4 * (lane >> 5);
 #pragma unroll
@@ -193,49 +209,81 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams P) 
         for (int i = 0; i < MT; ++i) {
             const int mb = m0 + (wm * MT + i) * 32 + rowq;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
-                if (!cv || m >= P.M) continue;
-                size_t pix;
-                if (os == 1) {
-                    pix = (size_t)m;
-                } else {
-                    const int n = m / HoWo;
-                    const int rr = m - n * HoWo;
-                    const int ho = rr / P.Wo;
-                    const int wo = rr - ho * P.Wo;
-                    pix = ((size_t)n * P.Hy + (ho * os + oh)) * P.Wy + (wo * os + ow);
+            for (int rb = 0; rb < 16; rb += 8) {     // 8 rows at a time keeps the register footprint small
+                int pix[8];
+                bool ok[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = rb + q;
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    ok[q] = cv && m < P.M;
+                    if (os == 1) {
+                        pix[q] = m;
+                    } else {
+                        const int n = m / HoWo;
+                        const int rr = m - n * HoWo;
+                        const int ho = rr / P.Wo;
+                        const int wo = rr - ho * P.Wo;
+                        pix[q] = (n * P.Hy + (ho * os + oh)) * P.Wy + (wo * os + ow);
+                    }
                 }
-                float v = acc[i][j][r] + bv;
-                if (P.mask) v = (P.mask[pix * P.ldm + co] > 0.f) ? v : 0.f;
-                if (P.res) v += P.res[pix * P.ldr + co];
-                if (P.relu_out) v = fmaxf(v, 0.f);
-                P.y[pix * P.ldy + co] = v;
+                float mk[8], rs[8];
+                if (maskp) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) mk[q] = ok[q] ? maskp[(size_t)pix[q] * P.ldm + co] : 0.f;
+                }
+                if (resp) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) rs[q] = ok[q] ? resp[(size_t)pix[q] * P.ldr + co] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float v = acc[i][j][rb + q] + bv;
+                    if (maskp) v = (mk[q] > 0.f) ? v : 0.f;
+                    if (resp) v += rs[q];
+                    if (P.relu_out) v = fmaxf(v, 0.f);
+                    if (ok[q]) yp[(size_t)pix[q] * P.ldy + co] = v;
+                }
             }
         }
     }
 }
 
-template <int WAVES_M, int WAVES_N, int MT, int NT>
+template <int WAVES_M, int WAVES_N, int MT, int NT, int BK>
 static int launch_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
     constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
-    const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
-    auto kern = conv_gemm_kernel<WAVES_M, WAVES_N, MT, NT>;
+    const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
+    auto kern = conv_gemm_kernel<WAVES_M, WAVES_N, MT, NT, BK>;
     allow_big_lds(kern, lds);
-    dim3 grid((P.M + BM - 1) / BM, (P.Co + BN - 1) / BN, P.phases);
+    dim3 grid(((P.M + BM - 1) / BM) * ((P.Co + BN - 1) / BN) * P.phases);
     const char *name = "conv_gemm";
     if (prof_enabled())
-        name = prof_label("conv_gemm<%dx%d>|M=%d,N=%d,K=%d,k%d,s%d,ph%d", BM, BN, P.M, P.Co, P.K, P.KH, P.stride, P.phases);
+        name = prof_label("conv_gemm<%dx%dx%d>|M=%d,N=%d,K=%d,k%d,s%d,ph%d", BM, BN, BK, P.M, P.Co, P.K, P.KH, P.stride,
+                          P.phases);
     ProfScope prof(name, P.flops, P.bytes, s);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, P);
     return check_launch("conv_gemm_kernel");
 }
 
+static int tune(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 static int run_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
-    // tile choice by output-channel count (GEMM N): keep the matrix pipe fed with full tiles
-    if (P.Co > 64) return launch_conv_gemm<2, 2, 2, 2>(P, s);   // 128 x 128
-    if (P.Co > 32) return launch_conv_gemm<2, 2, 2, 1>(P, s);   // 128 x 64
-    return launch_conv_gemm<4, 1, 2, 1>(P, s);                  // 256 x 32
+    // Tile by output-channel count (GEMM N).  Chunk depth per tile measured on MI355X: the 128x128 tile is
+    // register-bound at 2 waves/SIMD and prefers BK=32; the narrower tiles run 4+ waves/SIMD with BK=16.
+    static const int bk128 = tune("VQ2_BK128", 32), bk64 = tune("VQ2_BK64", 16), bk32 = tune("VQ2_BK32", 16);
+    if (P.Co > 64) {
+        if (bk128 == 16) return launch_conv_gemm<2, 2, 2, 2, 16>(P, s);
+        return launch_conv_gemm<2, 2, 2, 2, 32>(P, s);                     // 128 x 128
+    }
+    if (P.Co > 32) {
+        if (bk64 == 32) return launch_conv_gemm<2, 2, 2, 1, 32>(P, s);
+        return launch_conv_gemm<2, 2, 2, 1, 16>(P, s);                     // 128 x 64
+    }
+    if (bk32 == 32) return launch_conv_gemm<4, 1, 1, 1, 32>(P, s);
+    return launch_conv_gemm<4, 1, 1, 1, 16>(P, s);                         // 128 x 32
 }
 
 // ------------------------------------------------------------------ weight packing

@@ -46,9 +46,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int k0 = blockIdx.x * BNK;
-    const int o0 = blockIdx.y * BMO;
-    const int split = blockIdx.z;
+    // 1-D grid, XCD-aware: the k-tiles and o-tiles of one split share its G/X pixels -> same L2
+    const int ktiles = (P.K + BNK - 1) / BNK;
+    const int otiles = (P.O + BMO - 1) / BMO;
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int k0 = (vid % ktiles) * BNK;
+    const int o0 = ((vid / ktiles) % otiles) * BMO;
+    const int split = vid / (ktiles * otiles);
     const int m_begin = split * P.rows_per_split;
     const int m_end = min(P.M, m_begin + P.rows_per_split);
 
@@ -68,6 +72,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
     }
     const int HoWo = P.Ho * P.Wo;
 
+    // (n, ho, wo) of this thread's X rows, advanced by 32 rows per chunk without divisions
+    int xn[X_LD], xho[X_LD], xwo[X_LD];
+#pragma unroll
+    for (int j = 0; j < X_LD; ++j) {
+        const int m = m_begin + x_r + j * X_RSTEP;
+        xn[j] = m / HoWo;
+        const int r = m - xn[j] * HoWo;
+        xho[j] = r / P.Wo;
+        xwo[j] = r - xho[j] * P.Wo;
+    }
     float4 rg[G_LD], rx[X_LD];
     auto load_chunk = [&](int mbase) {
 #pragma unroll
@@ -75,23 +89,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
             const int m = mbase + g_r + j * G_RSTEP;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (g_cv && m < m_end) v = *reinterpret_cast<const float4 *>(P.g + (size_t)m * P.ldg + g_c);
-            rg[j] = P.relu_g ? relu4(v) : v;
+            rg[j] = v;
         }
 #pragma unroll
         for (int j = 0; j < X_LD; ++j) {
             const int m = mbase + x_r + j * X_RSTEP;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (x_kv && m < m_end) {
-                const int n = m / HoWo;
-                const int r = m - n * HoWo;
-                const int ho = r / P.Wo;
-                const int wo = r - ho * P.Wo;
-                const int ih = ho * P.stride - P.pad + kh;
-                const int iw = wo * P.stride - P.pad + kw;
+                const int ih = xho[j] * P.stride - P.pad + kh;
+                const int iw = xwo[j] * P.stride - P.pad + kw;
                 if ((unsigned)ih < (unsigned)P.H && (unsigned)iw < (unsigned)P.W)
-                    v = *reinterpret_cast<const float4 *>(P.x + ((size_t)(n * P.H + ih) * P.W + iw) * P.ldx + ci);
+                    v = *reinterpret_cast<const float4 *>(P.x + ((size_t)(xn[j] * P.H + ih) * P.W + iw) * P.ldx + ci);
             }
-            rx[j] = P.relu_x ? relu4(v) : v;
+            rx[j] = v;  // ReLU applied at the LDS write, so the load is not waited for here
+            // next chunk: 32 rows further in (n, ho, wo) order
+            xwo[j] += WG_BKR;
+            while (xwo[j] >= P.Wo) {
+                xwo[j] -= P.Wo;
+                if (++xho[j] == P.Ho) { xho[j] = 0; ++xn[j]; }
+            }
         }
     };
     auto store_chunk = [&](int buf) {
@@ -99,10 +115,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
         float *xs = Xs + buf * WG_BKR * BNK;
 #pragma unroll
         for (int j = 0; j < G_LD; ++j)
-            *reinterpret_cast<float4 *>(gs + (g_r + j * G_RSTEP) * BMO + (tid % G_C4) * 4) = rg[j];
+            *reinterpret_cast<float4 *>(gs + (g_r + j * G_RSTEP) * BMO + (tid % G_C4) * 4) = P.relu_g ? relu4(rg[j]) : rg[j];
 #pragma unroll
         for (int j = 0; j < X_LD; ++j)
-            *reinterpret_cast<float4 *>(xs + (x_r + j * X_RSTEP) * BNK + (tid % X_C4) * 4) = rx[j];
+            *reinterpret_cast<float4 *>(xs + (x_r + j * X_RSTEP) * BNK + (tid % X_C4) * 4) = P.relu_x ? relu4(rx[j]) : rx[j];
     };
 
     f32x16 acc[MT][NT];
@@ -120,7 +136,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
     }
     __syncthreads();
     const int fr = lane & 31, fk = lane >> 5;
-    const bool do_bias = P.bias_ws != nullptr && blockIdx.x == 0 && tid < BMO;
+    const bool do_bias = P.bias_ws != nullptr && k0 == 0 && tid < BMO;
     float bsum = 0.f;
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
@@ -222,7 +238,8 @@ static WgradPlan plan_wgrad(const vq2_conv_desc *d) {
     p.bmo = p.O > 64 ? 128 : (p.O > 32 ? 64 : 32);
     const int bnk = p.bmo == 32 ? 256 : 128;
     const int tiles = ((p.K + bnk - 1) / bnk) * ((p.O + p.bmo - 1) / p.bmo);
-    int S = (512 + tiles - 1) / tiles;               // aim at ~2 workgroups per CU (slab traffic grows with S)
+    int S = 512 / tiles;                             // fill the 2 x 256 resident slots without a tail round
+    if (S < 1) S = 1;
     const int max_s = (p.M + 255) / 256;             // at least 8 chunks of 32 rows per split
     if (S > max_s) S = max_s;
     if (S > 512) S = 512;
@@ -240,7 +257,7 @@ static int launch_wgrad(const WgradParams &P, int S, hipStream_t s) {
     const size_t lds = (size_t)2 * WG_BKR * (BMO + BNK) * sizeof(float);
     auto kern = wgrad_kernel<WAVES_M, WAVES_N, MT, NT>;
     allow_big_lds(kern, lds);
-    dim3 grid((P.K + BNK - 1) / BNK, (P.O + BMO - 1) / BMO, S);
+    dim3 grid(((P.K + BNK - 1) / BNK) * ((P.O + BMO - 1) / BMO) * S);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, P);
     return check_launch("wgrad_kernel");
 }
