@@ -188,32 +188,57 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
     }
 }
 
-// sum slabs in split order; scatter [o][tap][i] (padded O x I) -> reference layout [Or][Ir][tap];
-// the last block also folds the bias partials
-__global__ void wgrad_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, int O, int I, int Or, int Ir,
-                                    int taps, int S, const float *__restrict__ bias_ws, float *__restrict__ db) {
+// Sum the slabs and scatter [o][tap][i] (padded O x I) -> reference layout [Or][Ir][tap].
+// 256 threads = 32 outputs x 8 split-lanes: lane g adds splits g, g+8, ... (4 loads in flight), the 8
+// partial sums are combined through LDS in a fixed order -> bit-reproducible, and latency is paid
+// S/32 times instead of S times.  The last workgroup also folds the bias partials.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, int O,
+                                                           int I, int Or, int Ir, int taps, int S,
+                                                           const float *__restrict__ bias_ws, float *__restrict__ db) {
+    __shared__ float part[8][33];
     const int K = taps * I;
     const int total = O * K;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
-        const int o = t / K, k = t - o * K;
-        const int tap = k / I, i = k - tap * I;
-        if (o >= Or || i >= Ir) continue;
+    const int lane = threadIdx.x & 31, g = threadIdx.x >> 5;
+    for (int base = blockIdx.x * 32; base < total; base += gridDim.x * 32) {
+        const int t = base + lane;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int z = 0;
-        for (; z + 4 <= S; z += 4) {
-            s0 += ws[(size_t)z * total + t];
-            s1 += ws[(size_t)(z + 1) * total + t];
-            s2 += ws[(size_t)(z + 2) * total + t];
-            s3 += ws[(size_t)(z + 3) * total + t];
+        if (t < total) {
+            int z = g;
+            for (; z + 24 < S; z += 32) {
+                s0 += ws[(size_t)z * total + t];
+                s1 += ws[(size_t)(z + 8) * total + t];
+                s2 += ws[(size_t)(z + 16) * total + t];
+                s3 += ws[(size_t)(z + 24) * total + t];
+            }
+            for (; z < S; z += 8) s0 += ws[(size_t)z * total + t];
         }
-        for (; z < S; ++z) s0 += ws[(size_t)z * total + t];
-        dw[((size_t)o * Ir + i) * taps + tap] = (s0 + s1) + (s2 + s3);
+        part[g][lane] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (g == 0 && t < total) {
+            float s = part[0][lane];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) s += part[q][lane];
+            const int o = t / K, k = t - o * K;
+            const int tap = k / I, i = k - tap * I;
+            if (o < Or && i < Ir) dw[((size_t)o * Ir + i) * taps + tap] = s;
+        }
+        __syncthreads();
     }
     if (db && bias_ws && blockIdx.x == gridDim.x - 1) {
-        for (int o = threadIdx.x; o < Or; o += blockDim.x) {
-            float s = 0.f;
-            for (int z = 0; z < S; ++z) s += bias_ws[(size_t)z * O + o];
-            db[o] = s;
+        for (int base = 0; base < Or; base += 32) {
+            const int o = base + lane;
+            float s0 = 0.f;
+            if (o < Or)
+                for (int z = g; z < S; z += 8) s0 += bias_ws[(size_t)z * O + o];
+            part[g][lane] = s0;
+            __syncthreads();
+            if (g == 0 && o < Or) {
+                float s = part[0][lane];
+#pragma unroll
+                for (int q = 1; q < 8; ++q) s += part[q][lane];
+                db[o] = s;
+            }
+            __syncthreads();
         }
     }
 }
@@ -221,7 +246,7 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ ws, float *__restr
 static int colsum_impl(const float *dy, int64_t rows, int C, int ld, float *db, int nout, float *ws, hipStream_t s);
 
 struct WgradPlan {
-    int O, I, K, M, S, rows_per_split, bmo;
+    int O, I, K, M, S, rows_per_split, bmo, bnk;
 };
 
 static WgradPlan plan_wgrad(const vq2_conv_desc *d) {
@@ -235,14 +260,22 @@ static WgradPlan plan_wgrad(const vq2_conv_desc *d) {
         p.M = d->N * d->H * d->W;
     }
     p.K = d->KH * d->KW * p.I;
-    p.bmo = p.O > 64 ? 128 : (p.O > 32 ? 64 : 32);
-    const int bnk = p.bmo == 32 ? 256 : 128;
-    const int tiles = ((p.K + bnk - 1) / bnk) * ((p.O + p.bmo - 1) / p.bmo);
-    int S = 512 / tiles;                             // fill the 2 x 256 resident slots without a tail round
-    if (S < 1) S = 1;
+    // output tile (o x k): the candidate that wastes the least padded work, larger tile on ties
+    static const int cand[5][2] = {{128, 128}, {64, 128}, {32, 256}, {128, 32}, {64, 64}};
+    long best = -1;
+    for (int c = 0; c < 5; ++c) {
+        const long po = (p.O + cand[c][0] - 1) / cand[c][0] * cand[c][0];
+        const long pk = (p.K + cand[c][1] - 1) / cand[c][1] * cand[c][1];
+        const long work = po * pk;
+        if (best < 0 || work < best) { best = work; p.bmo = cand[c][0]; p.bnk = cand[c][1]; }
+    }
+    const int tiles = ((p.K + p.bnk - 1) / p.bnk) * ((p.O + p.bmo - 1) / p.bmo);
+    const int lds = 2 * WG_BKR * (p.bmo + p.bnk) * 4;
+    int per_cu = (160 * 1024) / lds;                 // resident workgroups per CU (LDS-bound), at most 4
+    if (per_cu > 4) per_cu = 4;
+    int S = (256 * per_cu) / tiles;                  // fill the resident slots without a tail round
     const int max_s = (p.M + 255) / 256;             // at least 8 chunks of 32 rows per split
     if (S > max_s) S = max_s;
-    if (S > 512) S = 512;
     if (S < 1) S = 1;
     int rps = (p.M + S - 1) / S;
     rps = (rps + 31) / 32 * 32;
@@ -373,14 +406,16 @@ extern "C" int vq2_conv_wgrad(const vq2_conv_desc *d, int flags, const float *x,
     const double pix_out_ = d->transposed ? 4.0 * pix_in_ : (double)P.M;
     const double macs_ = d->transposed ? pix_in_ * 16.0 * cir_ * cor_ : pix_out_ * d->KH * d->KW * cir_ * cor_;
     const char *pname = "wgrad";
-    if (prof_enabled()) pname = prof_label("wgrad<%d>|O=%d,K=%d,M=%d,S=%d,k%d", p.bmo, p.O, p.K, p.M, p.S, d->KH);
+    if (prof_enabled()) pname = prof_label("wgrad<%dx%d>|O=%d,K=%d,M=%d,S=%d,k%d", p.bmo, p.bnk, p.O, p.K, p.M, p.S, d->KH);
     ProfScope prof(pname, 2.0 * macs_, 4.0 * (pix_in_ * cir_ + pix_out_ * cor_ + cir_ * cor_ * d->KH * d->KW), s);
-    if (p.bmo == 128) e = launch_wgrad<2, 2, 2, 2>(P, p.S, s);       // 128(o) x 128(k)
-    else if (p.bmo == 64) e = launch_wgrad<1, 4, 2, 1>(P, p.S, s);   // 64 x 128
-    else e = launch_wgrad<1, 4, 1, 2>(P, p.S, s);                    // 32 x 256
+    if (p.bmo == 128 && p.bnk == 128) e = launch_wgrad<2, 2, 2, 2>(P, p.S, s);
+    else if (p.bmo == 64 && p.bnk == 128) e = launch_wgrad<1, 4, 2, 1>(P, p.S, s);
+    else if (p.bmo == 32) e = launch_wgrad<1, 4, 1, 2>(P, p.S, s);      // 32 x 256
+    else if (p.bmo == 128) e = launch_wgrad<4, 1, 1, 1>(P, p.S, s);     // 128 x 32 (1x1 convs with few inputs)
+    else e = launch_wgrad<2, 2, 1, 1>(P, p.S, s);                       // 64 x 64
     if (e) return e;
     const int total = p.O * p.K;
-    const int blocks = (total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048;
+    const int blocks = (total + 31) / 32 < 4096 ? (total + 31) / 32 : 4096;
     const int cir = d->Cir ? d->Cir : d->Ci, cor = d->Cor ? d->Cor : d->Co;
     const int Or = d->transposed ? cir : cor, Ir = d->transposed ? cor : cir;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, P.ws, dw, p.O, p.I, Or, Ir, d->KH * d->KW,
