@@ -274,6 +274,14 @@ static int run_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
     // Tile by output-channel count (GEMM N).  Chunk depth per tile measured on MI355X: the 128x128 tile is
     // register-bound at 2 waves/SIMD and prefers BK=32; the narrower tiles run 4+ waves/SIMD with BK=16.
     static const int bk128 = tune("VQ2_BK128", 32), bk64 = tune("VQ2_BK64", 16), bk32 = tune("VQ2_BK32", 16);
+    static const int small_m = tune("VQ2_SMALL_M", 1);
+    // few row tiles (the 32x32-resolution layers): halve the tile height so every CU still holds >= 2
+    // workgroups and the matrix pipe of a SIMD always has a second wave to switch to
+    const long wgs128 = (long)((P.M + 127) / 128) * ((P.Co + 127) / 128) * P.phases;
+    if (small_m && wgs128 < 400 && P.Co > 32) {
+        if (P.Co > 64) return launch_conv_gemm<2, 2, 1, 2, 16>(P, s);      // 64 x 128
+        return launch_conv_gemm<2, 2, 1, 1, 16>(P, s);                     // 64 x 64
+    }
     if (P.Co > 64) {
         if (bk128 == 16) return launch_conv_gemm<2, 2, 2, 2, 16>(P, s);
         return launch_conv_gemm<2, 2, 2, 2, 32>(P, s);                     // 128 x 128

@@ -333,13 +333,26 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__rest
     }
 }
 
-__global__ void colsum_final_kernel(const float *__restrict__ part, int nblocks, int C, int nout,
-                                    float *__restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nout) return;
-    float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * C + c];
-    out[c] = s;
+// 256 threads = 32 columns x 8 lanes over the partial blocks; fixed combine order (reproducible)
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restrict__ part, int nblocks, int C, int nout,
+                                                           float *__restrict__ out) {
+    __shared__ float red[8][33];
+    const int lane = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + lane;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < nout) {
+        int b = g;
+        for (; b + 8 < nblocks; b += 16) { s0 += part[(size_t)b * C + c]; s1 += part[(size_t)(b + 8) * C + c]; }
+        for (; b < nblocks; b += 8) s0 += part[(size_t)b * C + c];
+    }
+    red[g][lane] = s0 + s1;
+    __syncthreads();
+    if (g == 0 && c < nout) {
+        float s = red[0][lane];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) s += red[q][lane];
+        out[c] = s;
+    }
 }
 
 static int colsum_impl(const float *dy, int64_t rows, int C, int ld, float *db, int nout, float *ws, hipStream_t s) {
@@ -350,7 +363,7 @@ static int colsum_impl(const float *dy, int64_t rows, int C, int ld, float *db, 
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nb), dim3(256), (size_t)nrg * C * sizeof(float), s, dy, rows,
                        C, ld, rpb, ws);
     if (int e = check_launch("colsum_partial_kernel")) return e;
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((nout + 255) / 256), dim3(256), 0, s, ws, (int)nb, C, nout, db);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((nout + 31) / 32), dim3(256), 0, s, ws, (int)nb, C, nout, db);
     return check_launch("colsum_final_kernel");
 }
 
