@@ -178,15 +178,14 @@ __global__ __launch_bounds__(256, (BK == 16 && MT * NT == 4) ? 3 : 1) void conv_
             for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const float4 *>(a + i * 32 * LDK + k8 * 8);
 #pragma unroll
             for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const float4 *>(b + j * 32 * LDK + k8 * 8);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
-                }
+            // round-robin over the MT*NT independent accumulators: consecutive MFMAs never depend on each other
+#define VQ2_MFMA_STEP(C)                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NT; ++j)                 \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].C, fb[j].C, acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(1);
+            VQ2_MFMA_STEP(x) VQ2_MFMA_STEP(y) VQ2_MFMA_STEP(z) VQ2_MFMA_STEP(w)
+            __builtin_amdgcn_s_setprio(0);
+#undef VQ2_MFMA_STEP
         }
         if (c + 1 < nchunks) store_chunk(buf ^ 1);
         __syncthreads();
@@ -287,6 +286,8 @@ static int run_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
         return launch_conv_gemm<2, 2, 2, 2, 32>(P, s);                     // 128 x 128
     }
     if (P.Co > 32) {
+        static const int tall64 = tune("VQ2_TALL64", 0);
+        if (tall64) return launch_conv_gemm<4, 1, 2, 2, 16>(P, s);         // 256 x 64: each wave 64 x 64
         if (bk64 == 32) return launch_conv_gemm<2, 2, 2, 1, 32>(P, s);
         return launch_conv_gemm<2, 2, 2, 1, 16>(P, s);                     // 128 x 64
     }
@@ -317,6 +318,107 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, float *__restric
             kh = 3 - 2 * (ab >> 1) - (phase >> 1); kw = 3 - 2 * (ab & 1) - (phase & 1);
         }
         p[t] = (o < Or && i < Ir) ? w[((o * Ir + i) * KH + kh) * KW + kw] : 0.f;
+    }
+}
+
+
+// ------------------------------------------------------------------ conv-transpose to <= 4 channels
+// The reconstruction layer (vqvae.py:157: ConvTranspose2d(64 -> 3, k4 s2 p1)) has 3 output channels:
+// as a GEMM it would fill 3/32 of an MFMA tile, and it is HBM-bound anyway (AI ~ 20).  Direct form on
+// the vector ALU: one thread per INPUT-grid position produces the 2x2 output pixels it owns
+// (sub-pixel phases) from its 3x3 input neighbourhood.  The neighbourhood is staged through LDS in
+// 16-channel slices (coalesced 16-byte loads, ReLU fused); weights are wave-uniform, so they come
+// through the scalar cache as SGPR operands of the FMAs.
+constexpr int T3_TH = 4, T3_TW = 64, T3_CC = 16, T3_LD = 20;   // tile 4 x 64 positions, 16-ch slices, LDS pitch 20
+
+__global__ __launch_bounds__(256) void convT_small_kernel(const float *__restrict__ x, int ldx,
+                                                          const float *__restrict__ wk,   // [16 taps][4 co][Ci]
+                                                          const float *__restrict__ bias, int nbias,
+                                                          float *__restrict__ y, int ldy, int H, int W, int Ci,
+                                                          int relu_in) {
+    __shared__ __attribute__((aligned(16))) float xs[(T3_TH + 2) * (T3_TW + 2) * T3_LD];
+    const int t = threadIdx.x;
+    const int ti = t / T3_TW, tj = t % T3_TW;
+    const int i0 = blockIdx.y * T3_TH, j0 = blockIdx.x * T3_TW, n = blockIdx.z;
+    constexpr int HP = (T3_TH + 2) * (T3_TW + 2);
+    float acc[2][2][3];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[a][b][c] = 0.f;
+
+    for (int c0 = 0; c0 < Ci; c0 += T3_CC) {
+        __syncthreads();
+        for (int q = t; q < HP * (T3_CC / 4); q += 256) {
+            const int px = q / (T3_CC / 4), f = q % (T3_CC / 4);
+            const int gi = i0 - 1 + px / (T3_TW + 2), gj = j0 - 1 + px % (T3_TW + 2);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)gi < (unsigned)H && (unsigned)gj < (unsigned)W)
+                v = *reinterpret_cast<const float4 *>(x + ((size_t)(n * H + gi) * W + gj) * ldx + c0 + f * 4);
+            if (relu_in) v = relu4(v);
+            *reinterpret_cast<float4 *>(xs + px * T3_LD + f * 4) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int di = 0; di < 3; ++di)
+#pragma unroll
+            for (int dj = 0; dj < 3; ++dj) {
+                const float *p = xs + ((ti + di) * (T3_TW + 2) + tj + dj) * T3_LD;
+                float v[T3_CC];
+#pragma unroll
+                for (int f = 0; f < T3_CC / 4; ++f) {
+                    const float4 q4 = *reinterpret_cast<const float4 *>(p + f * 4);
+                    v[f * 4] = q4.x; v[f * 4 + 1] = q4.y; v[f * 4 + 2] = q4.z; v[f * 4 + 3] = q4.w;
+                }
+                // output row phase ph uses tap row a = di - ph (a in {0,1}), kernel row kh = 3 - 2a - ph
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) {
+                    const int a = di - ph;
+                    if (a < 0 || a > 1) continue;
+#pragma unroll
+                    for (int pw = 0; pw < 2; ++pw) {
+                        const int b = dj - pw;
+                        if (b < 0 || b > 1) continue;
+                        const int tap = (3 - 2 * a - ph) * 4 + (3 - 2 * b - pw);
+#pragma unroll
+                        for (int co = 0; co < 3; ++co) {
+                            const float *wr = wk + ((size_t)tap * 4 + co) * Ci + c0;   // wave-uniform -> scalar loads
+                            float s = acc[ph][pw][co];
+#pragma unroll
+                            for (int k = 0; k < T3_CC; ++k) s = fmaf(v[k], wr[k], s);
+                            acc[ph][pw][co] = s;
+                        }
+                    }
+                }
+            }
+    }
+    const int i = i0 + ti, j = j0 + tj;
+    if (i < H && j < W) {
+        const float b0 = (bias && nbias > 0) ? bias[0] : 0.f, b1 = (bias && nbias > 1) ? bias[1] : 0.f,
+                    b2 = (bias && nbias > 2) ? bias[2] : 0.f;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+            for (int pw = 0; pw < 2; ++pw) {
+                const size_t pix = ((size_t)n * 2 * H + 2 * i + ph) * (2 * W) + 2 * j + pw;
+                *reinterpret_cast<float4 *>(y + pix * ldy) =
+                    make_float4(acc[ph][pw][0] + b0, acc[ph][pw][1] + b1, acc[ph][pw][2] + b2, 0.f);
+            }
+    }
+}
+
+static bool use_convT_small(const vq2_conv_desc *d) {
+    return d->transposed && d->Co == 4 && d->Cor >= 1 && d->Cor <= 3 && d->Ci % 16 == 0 && d->N <= 65535;
+}
+
+// mode 3: w[Ci][Cor][4][4] -> p[kh*4+kw][4][Ci]  (row co = 3 is zero)
+__global__ void pack_convT_small_kernel(const float *__restrict__ w, float *__restrict__ p, int Ci, int Cor) {
+    const int total = 16 * 4 * Ci;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const int ci = t % Ci, co = (t / Ci) % 4, tap = t / (4 * Ci);
+        p[t] = co < Cor ? w[((size_t)ci * Cor + co) * 16 + tap] : 0.f;
     }
 }
 
@@ -361,6 +463,11 @@ extern "C" int vq2_pack_weight(const vq2_conv_desc *d, int which, const float *w
     VQ2_REQUIRE(w && packed, "pack_weight: null pointer");
     VQ2_REQUIRE(which == VQ2_PACK_FWD || which == VQ2_PACK_DGRAD, "pack_weight: bad `which`");
     const int cir = d->Cir ? d->Cir : d->Ci, cor = d->Cor ? d->Cor : d->Co;
+    if (which == VQ2_PACK_FWD && use_convT_small(d)) {
+        hipLaunchKernelGGL(pack_convT_small_kernel, dim3((16 * 4 * d->Ci + 255) / 256), dim3(256), 0, to_stream(stream), w,
+                           packed, d->Ci, cor);
+        return check_launch("pack_convT_small_kernel");
+    }
     int mode, Or, Ir, Op, Ip;
     if (!d->transposed) {
         Or = cor; Ir = cir; Op = d->Co; Ip = d->Ci;   // w is [Co][Ci][KH][KW]
@@ -383,6 +490,18 @@ extern "C" int vq2_conv_fwd(const vq2_conv_desc *d, int flags, const float *x, c
     VQ2_REQUIRE(x && wp && y, "conv_fwd: null pointer");
     VQ2_REQUIRE(aligned16(x) && aligned16(wp) && aligned16(y), "conv_fwd: pointers must be 16-byte aligned");
     VQ2_REQUIRE(!residual || (ldres >= d->Co), "conv_fwd: ldres < Co");
+    if (use_convT_small(d) && !residual && !(flags & VQ2_RELU_OUT)) {
+        hipStream_t s = to_stream(stream);
+        const int cor = d->Cor ? d->Cor : d->Co;
+        const char *name = "convT_small";
+        if (prof_enabled()) name = prof_label("convT_small|N=%d,H=%d,W=%d,Ci=%d", d->N, d->H, d->W, d->Ci);
+        ProfScope prof(name, 2.0 * d->N * d->H * d->W * 16.0 * d->Ci * cor,
+                       4.0 * ((double)d->N * d->H * d->W * d->Ci + 4.0 * d->N * d->H * d->W * cor), s);
+        dim3 grid((d->W + T3_TW - 1) / T3_TW, (d->H + T3_TH - 1) / T3_TH, d->N);
+        hipLaunchKernelGGL(convT_small_kernel, grid, dim3(256), 0, s, x, d->ldx, wp, bias, cor, y, d->ldy, d->H, d->W, d->Ci,
+                           (flags & VQ2_RELU_IN) != 0);
+        return check_launch("convT_small_kernel");
+    }
     ConvGemmParams P{};
     P.x = x; P.w = wp; P.bias = bias; P.mask = nullptr; P.res = residual; P.y = y;
     P.N = d->N; P.H = d->H; P.W = d->W; P.Ci = d->Ci; P.ldx = d->ldx;
