@@ -80,6 +80,19 @@ typedef struct vq2_conv_desc {
 #define VQ2_PACK_DGRAD 1 /* operand of vq2_conv_dgrad */
 int vq2_pack_weight(const vq2_conv_desc *d, int which, const float *w, float *packed, vq2_stream_t stream);
 
+/* Re-packing every layer after an optimizer step in ONE launch: fill one job per (layer, which) on
+ * the host with vq2_pack_job_init, set job.offset to the running sum of job.numel, copy the array to
+ * the device once, then call vq2_pack_weights_batched(jobs_dev, njobs, sum of numel) every step. */
+typedef struct vq2_pack_job {
+    const float *w;  /* reference-layout weight (device)            */
+    float *packed;   /* destination panel (device), numel floats    */
+    int64_t offset;  /* start of this job in the batched index space */
+    int64_t numel;
+    int32_t Or, Ir, Op, Ip, KH, KW, mode, reserved;
+} vq2_pack_job;
+int vq2_pack_job_init(const vq2_conv_desc *d, int which, const float *w, float *packed, vq2_pack_job *job);
+int vq2_pack_weights_batched(const vq2_pack_job *jobs_dev, int32_t njobs, int64_t total, vq2_stream_t stream);
+
 /* y = [relu]( conv_or_convT([relu]x, w) + bias [+ residual] )
  * wp: VQ2_PACK_FWD packing of w.  bias may be NULL.  residual (same shape as y,
  * pixel stride ldres) may be NULL: the `out += input` of vqvae.py:94. */

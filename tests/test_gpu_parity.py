@@ -290,7 +290,7 @@ def test_full256_default_model(amd, golden):
     m.quantize_t.register_forward_hook(lambda mod, i, o: ids.__setitem__("t", o[2]))
     m.quantize_b.register_forward_hook(lambda mod, i, o: ids.__setitem__("b", o[2]))
     tr = amd.Stage1Trainer(m, lr=3e-4)
-    out = tr.step(img)
+    out = tr.step(img, return_dec=True)
     nt = int((ids["t"].cpu().numpy().astype(np.int16) != g["id_t"]).sum())
     nb = int((ids["b"].cpu().numpy().astype(np.int16) != g["id_b"]).sum())
     assert nt == 0 and nb == 0, f"index mismatches top={nt} bottom={nb}"

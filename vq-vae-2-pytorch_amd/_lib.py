@@ -15,6 +15,11 @@ class ConvDesc(C.Structure):
                 ("N", "H", "W", "Ci", "Co", "KH", "KW", "stride", "pad", "transposed", "ldx", "ldy", "Cir", "Cor")]
 
 
+class PackJob(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("packed", C.c_void_p), ("offset", C.c_int64), ("numel", C.c_int64)] + \
+               [(n, C.c_int32) for n in ("Or", "Ir", "Op", "Ip", "KH", "KW", "mode", "reserved")]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -30,6 +35,8 @@ def _load():
         "vq2_prof_enable": (C.c_int, [C.c_int]),
         "vq2_prof_report": (C.c_int, [C.c_char_p, SZ]),
         "vq2_pack_weight": (C.c_int, [DP, C.c_int, P, P, P]),
+        "vq2_pack_job_init": (C.c_int, [DP, C.c_int, P, P, C.POINTER(PackJob)]),
+        "vq2_pack_weights_batched": (C.c_int, [P, I32, I64, P]),
         "vq2_conv_fwd": (C.c_int, [DP, C.c_int, P, P, P, P, I32, P, P]),
         "vq2_conv_dgrad": (C.c_int, [DP, P, P, P, I32, P, I32, P, I32, P]),
         "vq2_conv_wgrad_workspace_bytes": (SZ, [DP]),

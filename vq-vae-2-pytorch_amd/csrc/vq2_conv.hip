@@ -295,33 +295,6 @@ static int run_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
     return launch_conv_gemm<4, 1, 1, 1, 16>(P, s);                         // 128 x 32
 }
 
-// ------------------------------------------------------------------ weight packing
-// w is the reference tensor [Or][Ir][KH][KW] (real channel counts); the packed panel uses the
-// padded counts Op >= Or, Ip >= Ir and zero-fills.
-// mode 0: -> p[Op][kh*KW+kw][Ip]
-// mode 1: -> p[Ip][(KH-1-kh)*KW+(KW-1-kw)][Op]                    (stride-1 data gradient)
-// mode 2: w[A][B][4][4] -> p[ph*2+pw][Bp][a*2+b][Ap],  kh = 3-2a-ph, kw = 3-2b-pw   (sub-pixel; A=dim0, B=dim1)
-__global__ void pack_weight_kernel(const float *__restrict__ w, float *__restrict__ p, int Or, int Ir, int Op, int Ip,
-                                   int KH, int KW, int mode) {
-    const int taps = KH * KW;
-    const int total = Op * Ip * taps;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
-        int o, i, kh, kw;
-        if (mode == 0) {
-            i = t % Ip; const int tap = (t / Ip) % taps; o = t / (Ip * taps);
-            kh = tap / KW; kw = tap % KW;
-        } else if (mode == 1) {
-            o = t % Op; const int tapf = (t / Op) % taps; i = t / (Op * taps);
-            kh = KH - 1 - tapf / KW; kw = KW - 1 - tapf % KW;
-        } else {
-            o = t % Op; const int ab = (t / Op) % 4; i = (t / (Op * 4)) % Ip; const int phase = t / (Op * 4 * Ip);
-            kh = 3 - 2 * (ab >> 1) - (phase >> 1); kw = 3 - 2 * (ab & 1) - (phase & 1);
-        }
-        p[t] = (o < Or && i < Ir) ? w[((o * Ir + i) * KH + kh) * KW + kw] : 0.f;
-    }
-}
-
-
 // ------------------------------------------------------------------ conv-transpose to <= 4 channels
 // The reconstruction layer (vqvae.py:157: ConvTranspose2d(64 -> 3, k4 s2 p1)) has 3 output channels:
 // as a GEMM it would fill 3/32 of an MFMA tile, and it is HBM-bound anyway (AI ~ 20).  Direct form on
@@ -413,15 +386,6 @@ static bool use_convT_small(const vq2_conv_desc *d) {
     return d->transposed && d->Co == 4 && d->Cor >= 1 && d->Cor <= 3 && d->Ci % 16 == 0 && d->N <= 65535;
 }
 
-// mode 3: w[Ci][Cor][4][4] -> p[kh*4+kw][4][Ci]  (row co = 3 is zero)
-__global__ void pack_convT_small_kernel(const float *__restrict__ w, float *__restrict__ p, int Ci, int Cor) {
-    const int total = 16 * 4 * Ci;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
-        const int ci = t % Ci, co = (t / Ci) % 4, tap = t / (4 * Ci);
-        p[t] = co < Cor ? w[((size_t)ci * Cor + co) * 16 + tap] : 0.f;
-    }
-}
-
 static int check_desc(const vq2_conv_desc *d) {
     VQ2_REQUIRE(d != nullptr, "conv desc is null");
     VQ2_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Ci > 0 && d->Co > 0, "conv desc: non-positive dims");
@@ -458,30 +422,87 @@ static void out_dims(const vq2_conv_desc *d, int &Ho, int &Wo) {
 
 using namespace vq2;
 
-extern "C" int vq2_pack_weight(const vq2_conv_desc *d, int which, const float *w, float *packed, vq2_stream_t stream) {
-    if (int e = check_desc(d)) return e;
-    VQ2_REQUIRE(w && packed, "pack_weight: null pointer");
-    VQ2_REQUIRE(which == VQ2_PACK_FWD || which == VQ2_PACK_DGRAD, "pack_weight: bad `which`");
+// mode 3 = pack_convT_small layout
+static int pack_job_of(const vq2_conv_desc *d, int which, vq2_pack_job *j) {
     const int cir = d->Cir ? d->Cir : d->Ci, cor = d->Cor ? d->Cor : d->Co;
+    j->KH = d->KH; j->KW = d->KW;
     if (which == VQ2_PACK_FWD && use_convT_small(d)) {
-        hipLaunchKernelGGL(pack_convT_small_kernel, dim3((16 * 4 * d->Ci + 255) / 256), dim3(256), 0, to_stream(stream), w,
-                           packed, d->Ci, cor);
-        return check_launch("pack_convT_small_kernel");
-    }
-    int mode, Or, Ir, Op, Ip;
-    if (!d->transposed) {
-        Or = cor; Ir = cir; Op = d->Co; Ip = d->Ci;   // w is [Co][Ci][KH][KW]
-        if (which == VQ2_PACK_FWD) mode = 0;
-        else mode = (d->stride == 1) ? 1 : 2;          // stride-2 dgrad = sub-pixel with A = Co (dim0), B = Ci (dim1)
+        j->mode = 3; j->Or = d->Ci; j->Ir = cor; j->Op = d->Ci; j->Ip = 4;
+    } else if (!d->transposed) {
+        j->Or = cor; j->Ir = cir; j->Op = d->Co; j->Ip = d->Ci;      // w is [Co][Ci][KH][KW]
+        j->mode = (which == VQ2_PACK_FWD) ? 0 : ((d->stride == 1) ? 1 : 2);
     } else {
-        Or = cir; Ir = cor; Op = d->Ci; Ip = d->Co;   // w is [Ci][Co][4][4]
-        mode = (which == VQ2_PACK_FWD) ? 2 : 0;        // dgrad: strided conv with O = Ci, I = Co
+        j->Or = cir; j->Ir = cor; j->Op = d->Ci; j->Ip = d->Co;      // w is [Ci][Co][4][4]
+        j->mode = (which == VQ2_PACK_FWD) ? 2 : 0;
     }
-    const int total = Op * Ip * d->KH * d->KW;
+    j->numel = (int64_t)j->Op * j->Ip * j->KH * j->KW;
+    return VQ2_OK;
+}
+
+__device__ __forceinline__ float pack_elem(const float *__restrict__ w, int t, int Or, int Ir, int Op, int Ip, int KH,
+                                           int KW, int mode) {
+    const int taps = KH * KW;
+    int o, i, kh, kw;
+    if (mode == 0) {
+        i = t % Ip; const int tap = (t / Ip) % taps; o = t / (Ip * taps);
+        kh = tap / KW; kw = tap % KW;
+    } else if (mode == 1) {
+        o = t % Op; const int tapf = (t / Op) % taps; i = t / (Op * taps);
+        kh = KH - 1 - tapf / KW; kw = KW - 1 - tapf % KW;
+    } else if (mode == 2) {
+        o = t % Op; const int ab = (t / Op) % 4; i = (t / (Op * 4)) % Ip; const int phase = t / (Op * 4 * Ip);
+        kh = 3 - 2 * (ab >> 1) - (phase >> 1); kw = 3 - 2 * (ab & 1) - (phase & 1);
+    } else {  // [tap][4][Ci]: o = ci (dim 0 of w), i = co (dim 1)
+        o = t % Op; i = (t / Op) % 4; const int tap = t / (4 * Op);
+        kh = tap / 4; kw = tap % 4;
+    }
+    return (o < Or && i < Ir) ? w[((o * Ir + i) * KH + kh) * KW + kw] : 0.f;
+}
+
+// all weight panels of a model in ONE launch: job j owns [offset_j, offset_j + numel_j) of the index space
+__global__ __launch_bounds__(256) void pack_batched_kernel(const vq2_pack_job *__restrict__ jobs, int njobs, int64_t total) {
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
+        int lo = 0, hi = njobs - 1;
+        while (lo < hi) {  // last job with offset <= g
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].offset <= g) lo = mid; else hi = mid - 1;
+        }
+        const vq2_pack_job j = jobs[lo];
+        const int t = (int)(g - j.offset);
+        j.packed[t] = pack_elem(j.w, t, j.Or, j.Ir, j.Op, j.Ip, j.KH, j.KW, j.mode);
+    }
+}
+
+extern "C" int vq2_pack_job_init(const vq2_conv_desc *d, int which, const float *w, float *packed, vq2_pack_job *job) {
+    if (int e = check_desc(d)) return e;
+    VQ2_REQUIRE(w && packed && job, "pack_job_init: null pointer");
+    VQ2_REQUIRE(which == VQ2_PACK_FWD || which == VQ2_PACK_DGRAD, "pack_job_init: bad `which`");
+    job->w = w; job->packed = packed; job->offset = 0;
+    return pack_job_of(d, which, job);
+}
+
+extern "C" int vq2_pack_weights_batched(const vq2_pack_job *jobs_dev, int32_t njobs, int64_t total, vq2_stream_t stream) {
+    VQ2_REQUIRE(jobs_dev && njobs > 0 && total > 0, "pack_weights_batched: bad arguments");
+    const int64_t b = (total + 255) / 256;
+    hipLaunchKernelGGL(pack_batched_kernel, dim3((unsigned)(b > 2048 ? 2048 : b)), dim3(256), 0, to_stream(stream), jobs_dev,
+                       njobs, total);
+    return check_launch("pack_batched_kernel");
+}
+
+__global__ void pack_single_kernel(const float *__restrict__ w, float *__restrict__ p, int Or, int Ir, int Op, int Ip,
+                                   int KH, int KW, int mode, int total) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x)
+        p[t] = pack_elem(w, t, Or, Ir, Op, Ip, KH, KW, mode);
+}
+
+extern "C" int vq2_pack_weight(const vq2_conv_desc *d, int which, const float *w, float *packed, vq2_stream_t stream) {
+    vq2_pack_job j;
+    if (int e = vq2_pack_job_init(d, which, w, packed, &j)) return e;
+    const int total = (int)j.numel;
     const int blocks = (total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, to_stream(stream), w, packed, Or, Ir, Op, Ip,
-                       d->KH, d->KW, mode);
-    return check_launch("pack_weight_kernel");
+    hipLaunchKernelGGL(pack_single_kernel, dim3(blocks), dim3(256), 0, to_stream(stream), w, packed, j.Or, j.Ir, j.Op, j.Ip,
+                       j.KH, j.KW, j.mode, total);
+    return check_launch("pack_single_kernel");
 }
 
 extern "C" int vq2_conv_fwd(const vq2_conv_desc *d, int flags, const float *x, const float *wp, const float *bias,

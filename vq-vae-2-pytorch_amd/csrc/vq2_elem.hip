@@ -43,6 +43,35 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float *__restri
     }
 }
 
+// C <= 4 with pixel stride 4 (the image / reconstruction): one thread per pixel, plane reads coalesce
+// across threads, one 16-byte store (resp. load) per pixel
+__global__ void nchw_to_nhwc4_kernel(const float *__restrict__ src, float4 *__restrict__ dst, int C, int64_t HW,
+                                     int64_t total) {
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = g / HW, p = g - n * HW;
+        const float *s = src + n * C * HW + p;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        v.x = s[0];
+        if (C > 1) v.y = s[HW];
+        if (C > 2) v.z = s[2 * HW];
+        if (C > 3) v.w = s[3 * HW];
+        dst[g] = v;
+    }
+}
+
+__global__ void nhwc4_to_nchw_kernel(const float4 *__restrict__ src, float *__restrict__ dst, int C, int64_t HW,
+                                     int64_t total) {
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = g / HW, p = g - n * HW;
+        const float4 v = src[g];
+        float *d = dst + n * C * HW + p;
+        d[0] = v.x;
+        if (C > 1) d[HW] = v.y;
+        if (C > 2) d[2 * HW] = v.z;
+        if (C > 3) d[3 * HW] = v.w;
+    }
+}
+
 __global__ void relu_bwd_kernel(const float *__restrict__ dy, int lddy, const float *__restrict__ y, int ldy,
                                 float *__restrict__ g, int ldg, int64_t pixels, int C4) {
     const int64_t total = pixels * C4;
@@ -146,6 +175,12 @@ using namespace vq2;
 extern "C" int vq2_nchw_to_nhwc(const float *src, float *dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t ld,
                                 vq2_stream_t stream) {
     VQ2_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && ld >= C, "nchw_to_nhwc: bad arguments");
+    if (ld == 4 && aligned16(dst)) {
+        const int64_t HW4 = (int64_t)H * W, total = HW4 * N;
+        hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(grid_for(total)), dim3(256), 0, to_stream(stream), src,
+                           reinterpret_cast<float4 *>(dst), C, HW4, total);
+        return check_launch("nchw_to_nhwc4_kernel");
+    }
     VQ2_REQUIRE(N <= 65535, "nchw_to_nhwc: batch > 65535");
     const int HW = H * W;
     dim3 grid((HW + 31) / 32, (ld + 31) / 32, N);
@@ -156,6 +191,12 @@ extern "C" int vq2_nchw_to_nhwc(const float *src, float *dst, int32_t N, int32_t
 extern "C" int vq2_nhwc_to_nchw(const float *src, float *dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t ld,
                                 vq2_stream_t stream) {
     VQ2_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && ld >= C, "nhwc_to_nchw: bad arguments");
+    if (ld == 4 && aligned16(src)) {
+        const int64_t HW4 = (int64_t)H * W, total = HW4 * N;
+        hipLaunchKernelGGL(nhwc4_to_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, to_stream(stream),
+                           reinterpret_cast<const float4 *>(src), dst, C, HW4, total);
+        return check_launch("nhwc4_to_nchw_kernel");
+    }
     VQ2_REQUIRE(N <= 65535, "nhwc_to_nchw: batch > 65535");
     const int HW = H * W;
     dim3 grid((HW + 31) / 32, (C + 31) / 32, N);

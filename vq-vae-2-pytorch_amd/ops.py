@@ -11,7 +11,7 @@ import ctypes as C
 import torch
 from torch.autograd import Function
 
-from ._lib import lib, check, ConvDesc
+from ._lib import lib, check, ConvDesc, PackJob
 
 VQ2_RELU_IN = 1
 VQ2_RELU_OUT = 2
@@ -141,6 +141,49 @@ def packed_weight(spec, weight, which):
     check(lib.vq2_pack_weight(C.byref(d), which, _p(wsrc), _p(buf), _stream()), "pack_weight")
     _pack_cache[key] = (ver, buf)
     return buf
+
+
+class PackPlan:
+    """Every (layer, fwd|dgrad) weight panel of a model re-packed by ONE launch per step
+    (vq2_pack_weights_batched) instead of one launch per panel; feeds the same cache that
+    packed_weight() reads, so the conv wrappers need no change."""
+
+    def __init__(self, layers):
+        """layers: iterable of (ConvSpec, weight Parameter, needs_dgrad)."""
+        import numpy as np
+        jobs = []
+        for spec, weight, needs_dgrad in layers:
+            for which in ((PACK_FWD, PACK_DGRAD) if needs_dgrad else (PACK_FWD,)):
+                jobs.append((spec, weight, which))
+        n = sum(s.ci * s.co * s.k * s.k for s, _, _ in jobs)
+        dev = jobs[0][1].device
+        self.flat = torch.empty(n, device=dev, dtype=torch.float32)
+        self.entries = []
+        arr = (PackJob * len(jobs))()
+        off = 0
+        for i, (spec, weight, which) in enumerate(jobs):
+            numel = spec.ci * spec.co * spec.k * spec.k
+            buf = self.flat[off:off + numel]
+            d = _desc(spec, 1, max(spec.k, 2), max(spec.k, 2), spec.ci, spec.co)
+            if not weight.is_contiguous():
+                raise RuntimeError("PackPlan: weights must be contiguous")
+            check(lib.vq2_pack_job_init(C.byref(d), which, _p(weight), _p(buf), C.byref(arr[i])), "pack_job_init")
+            arr[i].offset = off
+            assert arr[i].numel == numel
+            self.entries.append((spec, weight, which, buf))
+            off += numel
+        self.total = off
+        raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+        self.jobs_dev = torch.from_numpy(raw).to(dev)
+        self.njobs = len(jobs)
+        self._ptrs = [w.data_ptr() for _, w, _, _ in self.entries]
+
+    def run(self):
+        if any(w.data_ptr() != p for (_, w, _, _), p in zip(self.entries, self._ptrs)):
+            raise RuntimeError("PackPlan: a parameter was re-allocated; rebuild the plan")
+        check(lib.vq2_pack_weights_batched(_p(self.jobs_dev), self.njobs, self.total, _stream()), "pack_batched")
+        for spec, weight, which, buf in self.entries:
+            _pack_cache[(id(weight), which)] = ((weight.data_ptr(), weight._version, WEIGHT_EPOCH[0], spec), buf)
 
 
 def conv_forward(spec, x, weight, bias, flags=0, residual=None, out=None):
@@ -530,16 +573,18 @@ class Stage1LossFn(Function):
     """loss = MSE(dec, img) + 0.25 * diff.mean()  (train_vqvae.py:83-85) -> (loss, recon, latent)."""
 
     @staticmethod
-    def forward(ctx, dec, diff, img, weight):
+    def forward(ctx, dec, diff, img, weight, denom=None):
+        """`denom`: number of real elements when dec/img carry zero padding (NHWC4 image layout)."""
         _require_cuda(dec, "dec")
         dc = dec if dec.is_contiguous() else dec.contiguous()
         ic = img if img.is_contiguous() else img.contiguous()
         n = dc.numel()
+        denom = n if denom is None else int(denom)
         recon = torch.empty((), device=dec.device, dtype=torch.float32)
         grad = torch.empty_like(dc) if ctx.needs_input_grad[0] else None
         ws = torch.empty(lib.vq2_mse_workspace_bytes(n) // 4, device=dec.device, dtype=torch.float32)
-        check(lib.vq2_mse_fwd_bwd(_p(dc), _p(ic), n, n, None, _p(recon), _p(grad), _p(ws), ws.numel() * 4, _stream()),
-              "mse_fwd_bwd")
+        check(lib.vq2_mse_fwd_bwd(_p(dc), _p(ic), n, denom, None, _p(recon), _p(grad), _p(ws), ws.numel() * 4,
+                                  _stream()), "mse_fwd_bwd")
         if diff.numel() != 1:
             raise RuntimeError("stage1 loss expects the [1]-shaped latent loss of VQVAE.forward")
         latent = diff.detach().reshape(())  # mean of a single element
@@ -556,4 +601,4 @@ class Stage1LossFn(Function):
         (grad,) = ctx.saved_tensors
         d_dec = None if grad is None else _scale_by(grad, g)
         d_diff = _scale_by(torch.ones(ctx.diff_shape, device=g.device), g, ctx.weight) if ctx.needs_input_grad[1] else None
-        return d_dec, d_diff, None, None
+        return d_dec, d_diff, None, None, None

@@ -33,18 +33,32 @@ class Stage1Trainer:
         self.scheduler = None
         if sched == "cycle":  # train_vqvae.py:188-195
             self.scheduler = CycleScheduler(self.optimizer, lr, n_iter=n_iter, momentum=None, warmup_proportion=0.05)
+        # every weight panel (forward and data-gradient layouts) re-packed by one launch per step
+        layers = []
+        for name, mod in model.named_modules():
+            if hasattr(mod, "spec") and hasattr(mod, "weight") and not name.startswith("dec_ir"):
+                layers.append((mod.spec, mod.weight, name != "enc_b.blocks.0"))
+        self.pack_plan = ops.PackPlan(layers)
+        self.pack_plan.run()
         self.world = dist_fn.get_world_size()
         self.optimizer.grad_scale = 1.0 / self.world  # DDP averages gradients (train_vqvae.py:166-171)
         self.comm_stream = torch.cuda.Stream() if self.world > 1 else None
 
-    def step(self, img):
-        """One training step on this rank's batch; returns device scalars (no host sync)."""
+    def step(self, img, return_dec=False):
+        """One training step on this rank's batch (img: NCHW); returns device scalars (no host sync)."""
         model = self.model
         model.train()
         self.arena.zero_grad()
         self.arena.extra.zero_()
-        dec, diff = model(img)
-        loss, recon, latent = stage1_loss(dec, diff, img)
+        if hasattr(model, "forward_nhwc"):
+            # loss evaluated in the kernels' own NHWC4 layout: no layout conversion of the
+            # reconstruction or of its gradient (the zero pad lane contributes nothing)
+            x = ops.to_nhwc(img)
+            dec, diff = model.forward_nhwc(x)
+            loss, recon, latent = ops.Stage1LossFn.apply(dec, diff, x, LATENT_LOSS_WEIGHT, img.numel())
+        else:
+            dec, diff = model(img)
+            loss, recon, latent = stage1_loss(dec, diff, img)
         loss.backward()
         if self.world > 1:
             if not self.arena.grads_ready():
@@ -61,7 +75,12 @@ class Stage1Trainer:
         if self.scheduler is not None:
             self.scheduler.step()
         self.optimizer.step()
-        return {"loss": loss.detach(), "recon": recon, "latent": latent, "dec": dec.detach()}
+        self.pack_plan.run()
+        out = {"loss": loss.detach(), "recon": recon, "latent": latent}
+        if return_dec:
+            d = dec.detach()
+            out["dec"] = ops.from_nhwc(d, img.shape[1]) if hasattr(model, "forward_nhwc") else d
+        return out
 
     def state_dict(self):
         """Checkpoint in the reference's format (train_vqvae.py:205-206) plus optimizer state."""

@@ -299,13 +299,16 @@ class VQVAE(nn.Module):
         quant = ops.CatViewFn.apply(up, quant_b, cat)
         return self.dec.nhwc(quant)
 
-    def forward(self, input):
-        x = ops.to_nhwc(input)
+    def forward_nhwc(self, x):
+        """NHWC in ([N,H,W,ceil4(in_channel)], zero padded) -> (NHWC reconstruction, diff [1])."""
         n, h, w, _ = x.shape
         e = self._e
         cat = torch.empty((n, h // 4, w // 4, 2 * e), device=x.device, dtype=torch.float32)
         quant_t, quant_b, diff, _, _ = self._encode_nhwc(x, quant_b_out=cat[..., e:])
-        dec = self._decode_from(quant_t, cat, quant_b)
+        return self._decode_from(quant_t, cat, quant_b), diff
+
+    def forward(self, input):
+        dec, diff = self.forward_nhwc(ops.to_nhwc(input))
         return ops.from_nhwc(dec, self._in_channel), diff
 
     def decode(self, quant):
