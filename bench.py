@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--prof-all", action="store_true",
+                    help="bracket EVERY GEMM launch (per-shape table; perturbs the step by ~6%%); default: only "
+                         "the dominant kernel")
     ap.add_argument("--kernel-table", default="", help="write the per-kernel table (JSON) here")
     return ap.parse_args()
 
@@ -119,10 +122,11 @@ def main():
         out = trainer.step(img)
     barrier()
     if not args.no_prof:
-        lib.vq2_prof_enable(1)
+        lib.vq2_prof_enable(1 if (args.prof_all or args.kernel_table) else 2)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = trainer.step(img)
+    t_host = time.perf_counter() - t0   # host time to ENQUEUE the steps (launch-bound if close to dt)
     barrier()
     dt = time.perf_counter() - t0
     lib.vq2_prof_enable(0)
@@ -159,7 +163,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "global_batch": batch * world, "image": size, "n_embed": n_embed,
                        "parallelism": f"dp{world}"},
-            "final_loss": round(loss, 6),
+            "final_loss": round(loss, 6), "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 3),
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

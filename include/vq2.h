@@ -42,11 +42,12 @@ typedef void *vq2_stream_t;
 int vq2_version(void);
 const char *vq2_last_error(void);
 
-/* Measurement aid (bench.py): when enabled, every conv/wgrad/VQ launch is bracketed by two HIP
- * events on its own stream.  vq2_prof_report waits for them (the ONLY synchronising entry point),
- * writes one line per kernel "name launches total_ms algorithmic_flops algorithmic_bytes" and
- * clears the records. */
-int vq2_prof_enable(int on);
+/* Measurement aid (bench.py): level 1 brackets every conv/wgrad/VQ launch with two HIP events on its
+ * own stream, level 2 only the dominant kernel (the 128x128x32 conv tile) so that the timed region is
+ * barely perturbed, 0 = off.  vq2_prof_report waits for the events (the ONLY synchronising entry
+ * point), writes one line per kernel+shape "name launches total_ms algorithmic_flops
+ * algorithmic_bytes" and clears the records. */
+int vq2_prof_enable(int level);
 int vq2_prof_report(char *buf, size_t cap);
 
 /* ------------------------------------------------------------------ conv

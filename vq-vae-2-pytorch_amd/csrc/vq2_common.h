@@ -17,13 +17,14 @@ int check_launch(const char *what);
 
 // optional per-launch event profiling (vq2_prof_enable); see vq2_core.cpp
 bool prof_enabled();
+int prof_level();  // 0 off, 1 every instrumented launch, 2 only launches flagged `dominant`
 const char *prof_label(const char *fmt, ...);
 int prof_begin(const char *name, double flops, double bytes, hipStream_t s);
 void prof_end(int id, hipStream_t s);
 struct ProfScope {
     int id; hipStream_t s;
-    ProfScope(const char *name, double flops, double bytes, hipStream_t st)
-        : id(prof_enabled() ? prof_begin(name, flops, bytes, st) : -1), s(st) {}
+    ProfScope(const char *name, double flops, double bytes, hipStream_t st, bool dominant = false)
+        : id((prof_level() == 1 || (prof_level() == 2 && dominant)) ? prof_begin(name, flops, bytes, st) : -1), s(st) {}
     ~ProfScope() { if (id >= 0) prof_end(id, s); }
 };
 

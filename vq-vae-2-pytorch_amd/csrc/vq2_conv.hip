@@ -259,7 +259,7 @@ static int launch_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
     if (prof_enabled())
         name = prof_label("conv_gemm<%dx%dx%d>|M=%d,N=%d,K=%d,k%d,s%d,ph%d", BM, BN, BK, P.M, P.Co, P.K, P.KH, P.stride,
                           P.phases);
-    ProfScope prof(name, P.flops, P.bytes, s);
+    ProfScope prof(name, P.flops, P.bytes, s, BM == 128 && BN == 128 && BK == 32);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, P);
     return check_launch("conv_gemm_kernel");
 }

@@ -34,6 +34,7 @@ static std::vector<ProfRec> g_prof;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_free;
 
 bool prof_enabled() { return g_prof_on.load(std::memory_order_relaxed) != 0; }
+int prof_level() { return g_prof_on.load(std::memory_order_relaxed); }
 
 // intern a formatted kernel+shape label (pointers stay valid for the life of the process)
 const char *prof_label(const char *fmt, ...) {
@@ -67,8 +68,8 @@ void prof_end(int id, hipStream_t s) {
 
 }  // namespace vq2
 
-extern "C" int vq2_prof_enable(int on) {
-    vq2::g_prof_on.store(on ? 1 : 0);
+extern "C" int vq2_prof_enable(int level) {
+    vq2::g_prof_on.store(level < 0 ? 0 : level);
     return VQ2_OK;
 }
 
