@@ -153,8 +153,19 @@ def main():
             dom = max(conv, key=lambda k: conv[k]["ms"])
             r = conv[dom]
             ach = r["flops"] / (r["ms"] * 1e-3) / 1e12
+            # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE doubled as the
+            # gfx950 guide prescribes, + WRITE_SIZE); they cannot be collected inside this process.
+            traffic, tsrc = None, None
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                    pm = json.load(f).get(dom)
+                if pm and pm.get("workload") == args.workload and pm.get("batch") == batch:
+                    traffic, tsrc = pm["bytes_per_launch"], pm["source"]
+            except OSError:
+                pass
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": tsrc, "algorithmic_bytes_per_launch": round(r["bytes"] / r["launches"]),
                     "launches_per_step": r["launches"] // args.steps,
                     "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2)}
         line = {
