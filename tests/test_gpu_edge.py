@@ -1,0 +1,182 @@
+"""GPU edge cases of the C-ABI path: ragged sizes, channel slices (pixel stride > C), fused flags,
+layout conversion, stand-alone modules, optimizer and checkpoint round trip -- each against the
+CPU oracle ops (plain torch fp32 on the same seeded inputs)."""
+import io
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import rng
+from oracle import vqvae_oracle as O
+
+pytestmark = pytest.mark.gpu
+RT, AT = 2e-4, 2e-5
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def close(a, b, rtol=RT, atol=AT, what=""):
+    np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=rtol, atol=atol, err_msg=what)
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import vqvae2_amd
+    return vqvae2_amd
+
+
+RAGGED = [
+    # kind, cin, cout, k, stride, pad, N, H, W
+    ("conv", 8, 12, 3, 1, 1, 1, 5, 7), ("conv", 20, 36, 3, 1, 1, 3, 9, 4), ("conv", 4, 8, 1, 1, 0, 2, 1, 1),
+    ("conv", 12, 8, 5, 1, 2, 1, 6, 6), ("conv", 16, 40, 7, 1, 3, 1, 8, 5), ("conv", 3, 8, 4, 2, 1, 2, 10, 6),
+    ("conv", 36, 132, 4, 2, 1, 1, 12, 8), ("conv", 5, 7, 3, 1, 1, 2, 4, 4), ("conv", 160, 136, 3, 1, 1, 1, 13, 11),
+    ("convT", 8, 12, 4, 2, 1, 1, 3, 5), ("convT", 20, 3, 4, 2, 1, 2, 5, 3), ("convT", 16, 2, 4, 2, 1, 1, 4, 70),
+    ("convT", 132, 68, 4, 2, 1, 1, 6, 7), ("convT", 5, 6, 4, 2, 1, 1, 2, 2),
+]
+
+
+def test_ragged_conv_shapes_fwd_and_grads(amd):
+    dev = torch.device("cuda:0")
+    for idx, (kind, cin, cout, k, s, p, n, h, w) in enumerate(RAGGED):
+        tag = f"rag{idx}"
+        x = t(rng.normal(3, tag + ".x", (n, cin, h, w)))
+        if kind == "conv":
+            m = amd.Conv2d(cin, cout, k, stride=s, padding=p)
+            wshape = (cout, cin, k, k)
+        else:
+            m = amd.ConvTranspose2d(cin, cout, k, stride=s, padding=p)
+            wshape = (cin, cout, k, k)
+        wt = t(rng.uniform(3, tag + ".w", wshape, -0.3, 0.3))
+        b = t(rng.uniform(3, tag + ".b", (cout,), -1, 1))
+        m.load_state_dict({"weight": wt, "bias": b})
+        m.to(dev)
+        xr = x.clone().requires_grad_(True)
+        wr, br = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        fn = F.conv2d if kind == "conv" else F.conv_transpose2d
+        yr = fn(xr, wr, br, stride=s, padding=p)
+        gy = t(rng.normal(3, tag + ".gy", tuple(yr.shape)))
+        yr.backward(gy)
+        xg = x.to(dev).requires_grad_(True)
+        y = m(xg)
+        assert tuple(y.shape) == tuple(yr.shape), tag
+        y.backward(gy.to(dev))
+        close(y, yr, what=tag + ".y")
+        close(xg.grad, xr.grad, what=tag + ".gx")
+        close(m.weight.grad, wr.grad, rtol=5e-4, atol=1e-4, what=tag + ".gw")
+        close(m.bias.grad, br.grad, rtol=5e-4, atol=1e-4, what=tag + ".gb")
+
+
+def test_channel_slices_and_fused_flags(amd):
+    """conv reading a channel slice, writing into a channel slice of a wider buffer, with fused
+    ReLU-in / residual / ReLU-out (what torch.cat + ResBlock become), against unfused torch ops."""
+    from vqvae2_amd import ops
+    dev = torch.device("cuda:0")
+    n, h, w, ci, co = 2, 6, 5, 12, 8
+    wide_in = t(rng.normal(5, "sl.in", (n, h, w, 20))).to(dev)
+    x = wide_in[..., 4:16]                                   # pixel stride 20, 12 channels
+    wide_out = torch.full((n, h, w, 24), 7.0, device=dev)
+    res = t(rng.normal(5, "sl.res", (n, h, w, co))).to(dev)
+    wt = t(rng.uniform(5, "sl.w", (co, ci, 3, 3), -0.3, 0.3)).to(dev)
+    b = t(rng.uniform(5, "sl.b", (co,), -1, 1)).to(dev)
+    spec = ops.ConvSpec(False, ci, co, 3, 1, 1)
+    y = ops.conv_forward(spec, x, wt, b, ops.VQ2_RELU_IN | ops.VQ2_RELU_OUT, residual=res, out=wide_out[..., 8:16])
+    ref = F.relu(F.conv2d(F.relu(x.permute(0, 3, 1, 2).cpu()), wt.cpu(), b.cpu(), padding=1)
+                 + res.permute(0, 3, 1, 2).cpu()).permute(0, 2, 3, 1)
+    close(y, ref)
+    assert float(wide_out[..., :8].min()) == 7.0 and float(wide_out[..., 16:].max()) == 7.0   # neighbours untouched
+    # data gradient with fused ReLU mask + skip gradient, written into a slice
+    dy = t(rng.normal(5, "sl.dy", (n, h, w, co))).to(dev)
+    dx_wide = torch.zeros((n, h, w, 16), device=dev)
+    dx = ops.conv_dgrad(spec, (n, h, w, ci), dy, wt, mask=x, residual=wide_in[..., 0:12], out=dx_wide[..., 4:16])
+    xr = x.permute(0, 3, 1, 2).cpu().clone().requires_grad_(True)
+    F.conv2d(F.relu(xr), wt.cpu(), None, padding=1).backward(dy.permute(0, 3, 1, 2).cpu())
+    close(dx, xr.grad.permute(0, 2, 3, 1) + wide_in[..., 0:12].cpu())
+
+
+def test_layout_conversion_generic_channels(amd):
+    from vqvae2_amd import ops
+    dev = torch.device("cuda:0")
+    for c in (1, 3, 4, 6, 33, 130):
+        x = t(rng.normal(9, f"lay{c}", (2, c, 5, 37))).to(dev).requires_grad_(True)
+        y = ops.NchwToNhwc.apply(x)
+        assert y.shape[-1] == ops.ceil4(c)
+        close(y[..., :c], x.permute(0, 2, 3, 1), rtol=0, atol=0)
+        assert float(y.detach()[..., c:].abs().sum()) == 0.0
+        back = ops.NhwcToNchw.apply(y, c)
+        close(back, x, rtol=0, atol=0)
+        back.sum().backward()
+        close(x.grad, torch.ones_like(x), rtol=0, atol=0)
+
+
+def test_standalone_modules_and_channels_last_chaining(amd):
+    dev = torch.device("cuda:0")
+    x = t(rng.normal(4, "sm.x", (2, 16, 6, 6))).to(dev)
+    r = amd.ReLU()(x)
+    close(r, F.relu(x), rtol=0, atol=0)
+    c1 = amd.Conv2d(16, 32, 3, padding=1).to(dev)
+    c2 = amd.Conv2d(32, 8, 1).to(dev)
+    y1 = c1(x)                                               # NCHW-shaped, channels-last strides
+    assert tuple(y1.shape) == (2, 32, 6, 6) and y1.stride(1) == 1
+    y2 = c2(y1)                                              # consumed zero-copy
+    ref = F.conv2d(F.conv2d(x.cpu(), c1.weight.detach().cpu(), c1.bias.detach().cpu(), padding=1),
+                   c2.weight.detach().cpu(), c2.bias.detach().cpu())
+    close(y2, ref)
+    close(y2.contiguous(), ref)
+    q = amd.Quantize(16, 64).to(dev).eval()
+    flat = t(rng.normal(4, "sm.q", (10, 16))).to(dev)       # non-4D input, like any [..., D] tensor
+    out, diff, idx = q(flat)
+    assert tuple(out.shape) == (10, 16) and tuple(idx.shape) == (10,)
+    ro, rd, ri = O.quantize_forward(flat.cpu(), q.embed.cpu().clone(), torch.zeros(64), q.embed.cpu().clone(), False)
+    assert torch.equal(idx.cpu(), ri)
+    close(out, ro, rtol=1e-6, atol=1e-6)
+
+
+def test_fused_adam_matches_torch_adam(amd):
+    dev = torch.device("cuda:0")
+    ps = [torch.nn.Parameter(t(rng.normal(6, f"ad{i}", s)).to(dev)) for i, s in enumerate([(7,), (3, 5), (2, 3, 4, 4)])]
+    qs = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ps]
+    a = amd.FusedAdam(ps, lr=1e-2)
+    b = torch.optim.Adam(qs, lr=1e-2)
+    for step in range(4):
+        for i, (p, q) in enumerate(zip(ps, qs)):
+            g = t(rng.normal(6, f"adg{step}.{i}", tuple(p.shape)))
+            p.grad = g.to(dev)
+            q.grad = g.clone()
+        a.step()
+        b.step()
+    for p, q in zip(ps, qs):
+        close(p, q, rtol=1e-5, atol=1e-6)
+
+
+def test_checkpoint_round_trip_reference_format(amd):
+    """torch.save(model.state_dict()) / load_state_dict as at train_vqvae.py:173-182, 205-206."""
+    dev = torch.device("cuda:0")
+    cfg = O.TINY
+    kw = dict(channel=cfg.channel, n_res_block=cfg.n_res_block, n_res_channel=cfg.n_res_channel,
+              embed_dim=cfg.embed_dim, n_embed=cfg.n_embed)
+    m = amd.VQVAE(**kw)
+    m.load_state_dict(O.make_state(cfg, 77))
+    m.to(dev)
+    tr = amd.Stage1Trainer(m, lr=3e-4, sched="cycle", n_iter=100)
+    img = O.make_images(2, 32, 77).to(dev)
+    tr.step(img)
+    buf = io.BytesIO()
+    torch.save(m.state_dict(), buf)
+    buf.seek(0)
+    sd = torch.load(buf, map_location="cpu", weights_only=True)
+    assert list(sd.keys()) == list(O.state_spec(cfg).keys())
+    m2 = amd.VQVAE(**kw)
+    m2.load_state_dict(sd)
+    m2.to(dev).eval()
+    m.eval()
+    with torch.no_grad():
+        a, _ = m(img)
+        b, _ = m2(img)
+    close(a, b, rtol=0, atol=0)
+    # the same checkpoint drives the CPU oracle (i.e. the reference layout) to the same output
+    ref, _, _, _ = O.vqvae_forward({k: v.clone() for k, v in sd.items()}, cfg, img.cpu(), training=False)
+    close(a, ref)

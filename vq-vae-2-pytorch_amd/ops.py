@@ -223,14 +223,31 @@ def _grad_slot(param):
     return None if param is None else torch.empty_like(param, memory_format=torch.contiguous_format)
 
 
+# Stage1Trainer sets this to a side HIP stream: weight gradients are off the backward critical path
+# (only the optimizer consumes them), so they run concurrently with the next layers' data-gradient
+# launches and fill the SIMD slots those leave idle.  Only legal when the gradients land in arena
+# slots that nobody reads before the trainer joins the streams.
+WGRAD_STREAM = [None]
+
+
 def conv_wgrad(spec, x, dy, relu_in, weight, bias=None, want_dw=True, want_db=True):
     """(dw, db) in the reference layouts; the bias gradient is fused into the same launches."""
     n, h, w, _ = x.shape
     d = _desc(spec, n, h, w, ld_of(x), ld_of(dy))
     nbytes = lib.vq2_conv_wgrad_workspace_bytes(C.byref(d))
-    ws = torch.empty(max(nbytes // 4, 4), device=x.device, dtype=torch.float32)
     dw = _grad_slot(weight)
     db = _grad_slot(bias) if (bias is not None and want_db) else None
+    side = WGRAD_STREAM[0]
+    if side is not None and getattr(weight, "_vq2_grad", None) is not None:
+        side.wait_event(torch.cuda.current_stream().record_event())
+        with torch.cuda.stream(side):
+            ws = torch.empty(max(nbytes // 4, 4), device=x.device, dtype=torch.float32)
+            check(lib.vq2_conv_wgrad(C.byref(d), VQ2_RELU_IN if relu_in else 0, _p(x), _p(dy), _p(dw), _p(db), _p(ws),
+                                     nbytes, _stream()), "conv_wgrad")
+        x.record_stream(side)   # keep the caching allocator from recycling these while the side stream reads
+        dy.record_stream(side)
+        return (dw if want_dw else None), db
+    ws = torch.empty(max(nbytes // 4, 4), device=x.device, dtype=torch.float32)
     check(lib.vq2_conv_wgrad(C.byref(d), VQ2_RELU_IN if relu_in else 0, _p(x), _p(dy), _p(dw), _p(db), _p(ws), nbytes,
                              _stream()), "conv_wgrad")
     return (dw if want_dw else None), db

@@ -43,6 +43,8 @@ class Stage1Trainer:
         self.world = dist_fn.get_world_size()
         self.optimizer.grad_scale = 1.0 / self.world  # DDP averages gradients (train_vqvae.py:166-171)
         self.comm_stream = torch.cuda.Stream() if self.world > 1 else None
+        import os
+        self.wgrad_stream = torch.cuda.Stream() if os.environ.get("VQ2_WGRAD_STREAM", "0") != "0" else None
 
     def step(self, img, return_dec=False):
         """One training step on this rank's batch (img: NCHW); returns device scalars (no host sync)."""
@@ -59,7 +61,13 @@ class Stage1Trainer:
         else:
             dec, diff = model(img)
             loss, recon, latent = stage1_loss(dec, diff, img)
-        loss.backward()
+        ops.WGRAD_STREAM[0] = self.wgrad_stream
+        try:
+            loss.backward()
+        finally:
+            ops.WGRAD_STREAM[0] = None
+        if self.wgrad_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)   # all weight gradients have landed
         if self.world > 1:
             if not self.arena.grads_ready():
                 raise RuntimeError("Stage1Trainer: a gradient did not land in the flat arena")
