@@ -20,6 +20,12 @@ class PackJob(C.Structure):
                [(n, C.c_int32) for n in ("Or", "Ir", "Op", "Ip", "KH", "KW", "mode", "reserved")]
 
 
+class WgradJob(C.Structure):
+    _fields_ = [("ws", C.c_void_p), ("dw", C.c_void_p), ("bias_ws", C.c_void_p), ("db", C.c_void_p),
+                ("unit_offset", C.c_int64)] + \
+               [(n, C.c_int32) for n in ("O", "I", "Or", "Ir", "taps", "S", "n_units_w", "n_units_b")]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -41,6 +47,9 @@ def _load():
         "vq2_conv_dgrad": (C.c_int, [DP, P, P, P, I32, P, I32, P, I32, P]),
         "vq2_conv_wgrad_workspace_bytes": (SZ, [DP]),
         "vq2_conv_wgrad": (C.c_int, [DP, C.c_int, P, P, P, P, P, SZ, P]),
+        "vq2_conv_wgrad_partial": (C.c_int, [DP, C.c_int, P, P, P, P, SZ, P]),
+        "vq2_wgrad_job_init": (C.c_int, [DP, P, P, P, C.POINTER(WgradJob)]),
+        "vq2_wgrad_reduce_batched": (C.c_int, [P, I32, I64, P]),
         "vq2_colsum_workspace_bytes": (SZ, [I64, I32]),
         "vq2_colsum": (C.c_int, [P, I64, I32, I32, P, P, SZ, P]),
         "vq2_nchw_to_nhwc": (C.c_int, [P, P, I32, I32, I32, I32, I32, P]),

@@ -245,6 +245,56 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
 
 static int colsum_impl(const float *dy, int64_t rows, int C, int ld, float *db, int nout, float *ws, hipStream_t s);
 
+// All layers' slab reductions in ONE launch (the per-layer reductions are latency-bound and tiny).
+// Index space = "units" of 32 consecutive outputs; a job owns [unit_offset, unit_offset + n_units_w +
+// n_units_b): first the weight units, then the bias units.  Same 32 x 8 fixed-order scheme as above.
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const vq2_wgrad_job *__restrict__ jobs, int njobs,
+                                                                   int64_t total_units) {
+    __shared__ float part[8][33];
+    const int lane = threadIdx.x & 31, g = threadIdx.x >> 5;
+    for (int64_t u = blockIdx.x; u < total_units; u += gridDim.x) {
+        int lo = 0, hi = njobs - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].unit_offset <= u) lo = mid; else hi = mid - 1;
+        }
+        const vq2_wgrad_job j = jobs[lo];
+        const int lu = (int)(u - j.unit_offset);
+        const bool is_bias = lu >= j.n_units_w;
+        const int K = j.taps * j.I;
+        const int total = is_bias ? j.O : j.O * K;      // stride between splits
+        const int limit = is_bias ? j.Or : j.O * K;
+        const float *src = is_bias ? j.bias_ws : j.ws;
+        const int t = (is_bias ? lu - j.n_units_w : lu) * 32 + lane;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (t < limit) {
+            int z = g;
+            for (; z + 24 < j.S; z += 32) {
+                s0 += src[(size_t)z * total + t];
+                s1 += src[(size_t)(z + 8) * total + t];
+                s2 += src[(size_t)(z + 16) * total + t];
+                s3 += src[(size_t)(z + 24) * total + t];
+            }
+            for (; z < j.S; z += 8) s0 += src[(size_t)z * total + t];
+        }
+        part[g][lane] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (g == 0 && t < limit) {
+            float s = part[0][lane];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) s += part[q][lane];
+            if (is_bias) {
+                j.db[t] = s;
+            } else {
+                const int o = t / K, k = t - o * K;
+                const int tap = k / j.I, i = k - tap * j.I;
+                if (o < j.Or && i < j.Ir) j.dw[((size_t)o * j.Ir + i) * j.taps + tap] = s;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 struct WgradPlan {
     int O, I, K, M, S, rows_per_split, bmo, bnk;
 };
@@ -377,9 +427,10 @@ extern "C" size_t vq2_conv_wgrad_workspace_bytes(const vq2_conv_desc *d) {
     return (size_t)p.S * p.O * (p.K + 1) * sizeof(float) + vq2_colsum_workspace_bytes((int64_t)d->N * 4 * d->H * d->W, d->Co);
 }
 
-extern "C" int vq2_conv_wgrad(const vq2_conv_desc *d, int flags, const float *x, const float *dy, float *dw, float *db,
-                              void *ws, size_t ws_bytes, vq2_stream_t stream) {
-    VQ2_REQUIRE(d && x && dy && dw && ws, "conv_wgrad: null pointer");
+// slabs (+ bias partials); reduce == true also runs the per-layer reduction into dw/db
+static int wgrad_impl(const vq2_conv_desc *d, int flags, const float *x, const float *dy, float *dw, float *db, void *ws,
+                      size_t ws_bytes, vq2_stream_t stream, bool reduce) {
+    VQ2_REQUIRE(d && x && dy && ws && (dw || !reduce), "conv_wgrad: null pointer");
     VQ2_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Ci > 0 && d->Co > 0 && d->Ci % 4 == 0 && d->Co % 4 == 0,
                 "conv_wgrad: bad dims");
     VQ2_REQUIRE(d->ldx >= d->Ci && d->ldy >= d->Co && d->ldx % 4 == 0 && d->ldy % 4 == 0, "conv_wgrad: bad strides");
@@ -427,6 +478,13 @@ extern "C" int vq2_conv_wgrad(const vq2_conv_desc *d, int flags, const float *x,
     else if (p.bmo == 128) e = launch_wgrad<4, 1, 1, 1>(P, p.S, s);     // 128 x 32 (1x1 convs with few inputs)
     else e = launch_wgrad<2, 2, 1, 1>(P, p.S, s);                       // 64 x 64
     if (e) return e;
+    if (!reduce) {
+        if (db && d->transposed) {
+            const int cor2 = d->Cor ? d->Cor : d->Co;
+            return colsum_impl(dy, (int64_t)d->N * 4 * d->H * d->W, d->Co, d->ldy, db, cor2, colsum_ws, s);
+        }
+        return VQ2_OK;
+    }
     const int total = p.O * p.K;
     const int blocks = (total + 31) / 32 < 4096 ? (total + 31) / 32 : 4096;
     const int cir = d->Cir ? d->Cir : d->Ci, cor = d->Cor ? d->Cor : d->Co;
@@ -439,6 +497,43 @@ extern "C" int vq2_conv_wgrad(const vq2_conv_desc *d, int flags, const float *x,
         return colsum_impl(dy, rows, d->Co, d->ldy, db, cor, colsum_ws, s);
     }
     return VQ2_OK;
+}
+
+extern "C" int vq2_conv_wgrad(const vq2_conv_desc *d, int flags, const float *x, const float *dy, float *dw, float *db,
+                              void *ws, size_t ws_bytes, vq2_stream_t stream) {
+    return wgrad_impl(d, flags, x, dy, dw, db, ws, ws_bytes, stream, true);
+}
+
+extern "C" int vq2_conv_wgrad_partial(const vq2_conv_desc *d, int flags, const float *x, const float *dy, float *db,
+                                      void *ws, size_t ws_bytes, vq2_stream_t stream) {
+    return wgrad_impl(d, flags, x, dy, nullptr, db, ws, ws_bytes, stream, false);
+}
+
+extern "C" int vq2_wgrad_job_init(const vq2_conv_desc *d, const void *ws, float *dw, float *db, vq2_wgrad_job *job) {
+    VQ2_REQUIRE(d && ws && dw && job, "wgrad_job_init: null pointer");
+    const WgradPlan p = plan_wgrad(d);
+    const int cir = d->Cir ? d->Cir : d->Ci, cor = d->Cor ? d->Cor : d->Co;
+    const float *w = static_cast<const float *>(ws);
+    job->ws = w; job->dw = dw; job->db = nullptr; job->bias_ws = nullptr;
+    job->O = p.O; job->I = p.I; job->Or = d->transposed ? cir : cor; job->Ir = d->transposed ? cor : cir;
+    job->taps = d->KH * d->KW; job->S = p.S;
+    job->n_units_w = (p.O * p.K + 31) / 32;
+    job->n_units_b = 0;
+    if (db && !d->transposed) {   // conv-transpose bias gradients are produced by the partial call itself
+        job->db = db; job->bias_ws = w + (size_t)p.S * p.O * p.K;
+        job->n_units_b = (job->Or + 31) / 32;
+    }
+    job->unit_offset = 0;
+    return VQ2_OK;
+}
+
+extern "C" int vq2_wgrad_reduce_batched(const vq2_wgrad_job *jobs_dev, int32_t njobs, int64_t total_units,
+                                        vq2_stream_t stream) {
+    VQ2_REQUIRE(jobs_dev && njobs > 0 && total_units > 0, "wgrad_reduce_batched: bad arguments");
+    const unsigned blocks = (unsigned)(total_units < 8192 ? total_units : 8192);
+    hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3(blocks), dim3(256), 0, to_stream(stream), jobs_dev, njobs,
+                       total_units);
+    return check_launch("wgrad_reduce_batched_kernel");
 }
 
 extern "C" size_t vq2_colsum_workspace_bytes(int64_t rows, int32_t C) {

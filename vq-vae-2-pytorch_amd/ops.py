@@ -11,7 +11,7 @@ import ctypes as C
 import torch
 from torch.autograd import Function
 
-from ._lib import lib, check, ConvDesc, PackJob
+from ._lib import lib, check, ConvDesc, PackJob, WgradJob
 
 VQ2_RELU_IN = 1
 VQ2_RELU_OUT = 2
@@ -223,6 +223,66 @@ def _grad_slot(param):
     return None if param is None else torch.empty_like(param, memory_format=torch.contiguous_format)
 
 
+class WgradBatch:
+    """Deferred weight-gradient reduction for a whole backward pass: every conv_wgrad writes only its
+    split-K slabs into a persistent per-layer workspace; flush() reduces ALL layers with one launch
+    (vq2_wgrad_reduce_batched) straight into the ParamArena gradient slots."""
+
+    def __init__(self):
+        self.entries = {}
+        self.order = []
+        self.jobs_dev = None
+        self.total_units = 0
+        self.dirty = True
+
+    def launch(self, spec, x, dy, relu_in, weight, bias, want_db):
+        n, h, w, _ = x.shape
+        key = (id(weight), n, h, w, ld_of(x), ld_of(dy), relu_in)
+        d = _desc(spec, n, h, w, ld_of(x), ld_of(dy))
+        ent = self.entries.get(key)
+        if ent is None:
+            nbytes = lib.vq2_conv_wgrad_workspace_bytes(C.byref(d))
+            ws = torch.empty(max(nbytes // 4, 4), device=x.device, dtype=torch.float32)
+            dw = weight._vq2_grad
+            db = bias._vq2_grad if (bias is not None and want_db) else None
+            job = WgradJob()
+            check(lib.vq2_wgrad_job_init(C.byref(d), _p(ws), _p(dw), _p(db), C.byref(job)), "wgrad_job_init")
+            ent = {"ws": ws, "nbytes": nbytes, "job": job, "dw": dw, "db": db, "used": False}
+            self.entries[key] = ent
+            self.dirty = True
+        check(lib.vq2_conv_wgrad_partial(C.byref(d), VQ2_RELU_IN if relu_in else 0, _p(x), _p(dy), _p(ent["db"]),
+                                         _p(ent["ws"]), ent["nbytes"], _stream()), "conv_wgrad_partial")
+        if not ent["used"]:
+            ent["used"] = True
+            self.order.append(key)
+        dw, db = ent["dw"], ent["db"]
+        return dw.view_as(dw), (None if db is None else db.view_as(db))
+
+    def flush(self):
+        if not self.order:
+            return
+        sig = tuple(self.order)
+        if self.dirty or sig != getattr(self, "_sig", None):
+            import numpy as np
+            arr = (WgradJob * len(self.order))()
+            off = 0
+            for i, key in enumerate(self.order):
+                job = self.entries[key]["job"]
+                job.unit_offset = off
+                arr[i] = job
+                off += job.n_units_w + job.n_units_b
+            raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+            self.jobs_dev = torch.from_numpy(raw).to(self.entries[self.order[0]]["ws"].device)
+            self.total_units, self._sig, self.dirty = off, sig, False
+        check(lib.vq2_wgrad_reduce_batched(_p(self.jobs_dev), len(self.order), self.total_units, _stream()),
+              "wgrad_reduce_batched")
+        for key in self.order:
+            self.entries[key]["used"] = False
+        self.order = []
+
+
+WGRAD_BATCH = [None]
+
 # Stage1Trainer sets this to a side HIP stream: weight gradients are off the backward critical path
 # (only the optimizer consumes them), so they run concurrently with the next layers' data-gradient
 # launches and fill the SIMD slots those leave idle.  Only legal when the gradients land in arena
@@ -235,6 +295,12 @@ def conv_wgrad(spec, x, dy, relu_in, weight, bias=None, want_dw=True, want_db=Tr
     n, h, w, _ = x.shape
     d = _desc(spec, n, h, w, ld_of(x), ld_of(dy))
     nbytes = lib.vq2_conv_wgrad_workspace_bytes(C.byref(d))
+    batch = WGRAD_BATCH[0]
+    if batch is not None and getattr(weight, "_vq2_grad", None) is not None and \
+            (bias is None or getattr(bias, "_vq2_grad", None) is not None) and \
+            (bias is None or bias.numel() == spec.cout):
+        dw, db = batch.launch(spec, x, dy, relu_in, weight, bias, want_db)
+        return (dw if want_dw else None), db
     dw = _grad_slot(weight)
     db = _grad_slot(bias) if (bias is not None and want_db) else None
     side = WGRAD_STREAM[0]

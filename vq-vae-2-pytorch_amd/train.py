@@ -38,6 +38,7 @@ class Stage1Trainer:
         for name, mod in model.named_modules():
             if hasattr(mod, "spec") and hasattr(mod, "weight") and not name.startswith("dec_ir"):
                 layers.append((mod.spec, mod.weight, name != "enc_b.blocks.0"))
+        self.wgrad_batch = ops.WgradBatch()
         self.pack_plan = ops.PackPlan(layers)
         self.pack_plan.run()
         self.world = dist_fn.get_world_size()
@@ -62,10 +63,13 @@ class Stage1Trainer:
             dec, diff = model(img)
             loss, recon, latent = stage1_loss(dec, diff, img)
         ops.WGRAD_STREAM[0] = self.wgrad_stream
+        ops.WGRAD_BATCH[0] = self.wgrad_batch
         try:
             loss.backward()
         finally:
             ops.WGRAD_STREAM[0] = None
+            ops.WGRAD_BATCH[0] = None
+        self.wgrad_batch.flush()   # one launch reduces the split-K slabs of every layer into the arena
         if self.wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)   # all weight gradients have landed
         if self.world > 1:
