@@ -35,6 +35,8 @@ def _run(world, rank, imgs, steps):
     for _ in range(steps):
         out = tr.step(imgs.cuda())
     torch.cuda.synchronize()
+    if world > 1:   # the decoder-side gradient bucket went out from the backward hook (overlap path)
+        assert tr.split_off is not None and tr._bucket_sent
     return {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}, float(out["loss"])
 
 

@@ -231,8 +231,7 @@ class WgradBatch:
     def __init__(self):
         self.entries = {}
         self.order = []
-        self.jobs_dev = None
-        self.total_units = 0
+        self.tables = {}
         self.dirty = True
 
     def launch(self, spec, x, dy, relu_in, weight, bias, want_db):
@@ -262,7 +261,11 @@ class WgradBatch:
         if not self.order:
             return
         sig = tuple(self.order)
-        if self.dirty or sig != getattr(self, "_sig", None):
+        if self.dirty:
+            self.tables = {}
+            self.dirty = False
+        tab = self.tables.get(sig)
+        if tab is None:   # job table of this subset of layers: built and uploaded once, then reused every step
             import numpy as np
             arr = (WgradJob * len(self.order))()
             off = 0
@@ -272,10 +275,9 @@ class WgradBatch:
                 arr[i] = job
                 off += job.n_units_w + job.n_units_b
             raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
-            self.jobs_dev = torch.from_numpy(raw).to(self.entries[self.order[0]]["ws"].device)
-            self.total_units, self._sig, self.dirty = off, sig, False
-        check(lib.vq2_wgrad_reduce_batched(_p(self.jobs_dev), len(self.order), self.total_units, _stream()),
-              "wgrad_reduce_batched")
+            tab = (torch.from_numpy(raw).to(self.entries[self.order[0]]["ws"].device), off)
+            self.tables[sig] = tab
+        check(lib.vq2_wgrad_reduce_batched(_p(tab[0]), len(self.order), tab[1], _stream()), "wgrad_reduce_batched")
         for key in self.order:
             self.entries[key]["used"] = False
         self.order = []

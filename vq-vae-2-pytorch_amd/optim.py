@@ -32,15 +32,22 @@ class ParamArena:
         sizes = [(p.numel() + 3) // 4 * 4 for p in params]  # keep every slot 16-byte aligned
         self.n = sum(sizes)
         self.flat_p = torch.zeros(self.n, device=dev, dtype=torch.float32)
-        self.flat_g = torch.zeros(self.n + extra, device=dev, dtype=torch.float32)
-        self.extra = self.flat_g[self.n:]
+        # gradient buffer = [extra (VQ statistics) | parameter gradients in registration order]; backward
+        # produces gradients roughly in REVERSE registration order, so the tail of this buffer is
+        # complete first and can be all-reduced while the encoder is still back-propagating
+        self.n_extra = (extra + 3) // 4 * 4
+        self.flat_g = torch.zeros(self.n_extra + self.n, device=dev, dtype=torch.float32)
+        self.extra = self.flat_g[:extra]
+        self.gp = self.flat_g[self.n_extra:]
+        self.offset = {}
         off = 0
         with torch.no_grad():
             for p, sz in zip(params, sizes):
                 view = self.flat_p[off:off + p.numel()].view(p.shape)
                 view.copy_(p.data)
                 p.data = view
-                p._vq2_grad = self.flat_g[off:off + p.numel()].view(p.shape)
+                p._vq2_grad = self.gp[off:off + p.numel()].view(p.shape)
+                self.offset[id(p)] = off
                 off += sz
         ops.WEIGHT_EPOCH[0] += 1
 
@@ -73,7 +80,7 @@ class FusedAdam(torch.optim.Optimizer):
         if self.arena is not None and len(self.param_groups) == 1 and self.arena.grads_ready():
             self._t += 1
             a = self.arena
-            check(lib.vq2_adam_step(ops._p(a.flat_p), ops._p(a.flat_g), ops._p(self._m), ops._p(self._v), a.n,
+            check(lib.vq2_adam_step(ops._p(a.flat_p), ops._p(a.gp), ops._p(self._m), ops._p(self._v), a.n,
                                     lr, b1, b2, eps, self._t, self.grad_scale, s), "adam_step")
         else:
             for group in self.param_groups:

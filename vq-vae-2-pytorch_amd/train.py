@@ -45,7 +45,28 @@ class Stage1Trainer:
         self.optimizer.grad_scale = 1.0 / self.world  # DDP averages gradients (train_vqvae.py:166-171)
         self.comm_stream = torch.cuda.Stream() if self.world > 1 else None
         import os
+        # Overlap: when the gradients of the layers that back-propagate first (decoder side; they sit at the
+        # TAIL of the arena) are complete, their slice is all-reduced on the side stream while the
+        # encoder is still back-propagating; the head (encoder gradients + EMA statistics) follows.
+        self.split_off = None
+        self._late_seen = 0
+        self._bucket_sent = False
+        split = getattr(model, "quantize_conv_b", None)
+        if self.world > 1 and split is not None and os.environ.get("VQ2_DP_OVERLAP", "1") != "0":
+            self.split_off = self.arena.n_extra + self.arena.offset[id(split.weight)]
+            split.weight.register_post_accumulate_grad_hook(self._late_grad_ready)
+            split.bias.register_post_accumulate_grad_hook(self._late_grad_ready)
         self.wgrad_stream = torch.cuda.Stream() if os.environ.get("VQ2_WGRAD_STREAM", "0") != "0" else None
+
+    def _late_grad_ready(self, _param):
+        self._late_seen += 1
+        if self._late_seen == 2 and not self._bucket_sent:
+            self.wgrad_batch.flush()                      # reduce the split-K slabs produced so far
+            ev = torch.cuda.current_stream().record_event()
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                dist.all_reduce(self.arena.flat_g[self.split_off:])
+            self._bucket_sent = True
 
     def step(self, img, return_dec=False):
         """One training step on this rank's batch (img: NCHW); returns device scalars (no host sync)."""
@@ -62,6 +83,7 @@ class Stage1Trainer:
         else:
             dec, diff = model(img)
             loss, recon, latent = stage1_loss(dec, diff, img)
+        self._late_seen, self._bucket_sent = 0, False
         ops.WGRAD_STREAM[0] = self.wgrad_stream
         ops.WGRAD_BATCH[0] = self.wgrad_batch
         try:
@@ -80,7 +102,10 @@ class Stage1Trainer:
             ev = torch.cuda.current_stream().record_event()
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                dist.all_reduce(self.arena.flat_g)
+                if self._bucket_sent:
+                    dist.all_reduce(self.arena.flat_g[:self.split_off])
+                else:
+                    dist.all_reduce(self.arena.flat_g)
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         for q in self.quantizers:
             q.apply_deferred_update()
