@@ -195,6 +195,12 @@ int vq2_axpby(const float *a, const float *b, float alpha, float *dst, int64_t n
 /* dst = src * scalar[0] * alpha, scalar read on the device (upstream gradient of a loss) */
 int vq2_scale(const float *src, const float *scalar, float alpha, float *dst, int64_t n, vq2_stream_t stream);
 
+/* calibration only: register-resident fp32-MFMA loop (blocks x 256 threads, iters x 32 MFMAs per wave);
+ * 2*32*32*2 FLOP per MFMA.  Used by scripts/mfma_peak.py to measure the ceiling the chip sustains. */
+int vq2_debug_mfma_peak(float *scratch, int32_t blocks, int32_t iters, vq2_stream_t stream);
+/* diagnostic only: per-phase cycle stamps of the 128x128x32 conv tile into buf[16] (NULL = off) */
+int vq2_debug_set_stamps(unsigned long long *buf);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,6 +68,8 @@ def _load():
         "vq2_adam_step": (C.c_int, [P, P, P, P, I64, D, D, D, D, I32, D, P]),
         "vq2_axpby": (C.c_int, [P, P, F, P, I64, P]),
         "vq2_scale": (C.c_int, [P, P, F, P, I64, P]),
+        "vq2_debug_mfma_peak": (C.c_int, [P, I32, I32, P]),
+        "vq2_debug_set_stamps": (C.c_int, [P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch

@@ -41,12 +41,13 @@ struct ConvGemmParams {
     int relu_in, relu_out;
     int nbias;            // bias has nbias entries (real output channels)
     double flops, bytes;  // algorithmic work of this launch (for the profiler only)
+    unsigned long long *stamps;  // diagnostic build only (STAMP): per-phase cycle totals of workgroup 0
 };
 
 // BK = depth of one staged chunk; LDS rows are padded to BK+4 floats (144 B / 80 B), which makes the
 // ds_read_b128 fragment reads conflict-free (16-byte slot index = row*9 resp. row*5 mod 16).
-template <int WAVES_M, int WAVES_N, int MT, int NT, int BK>
-__global__ __launch_bounds__(256, (BK == 16 && MT * NT == 4) ? 3 : 1) void conv_gemm_kernel(const ConvGemmParams P) {
+template <int WAVES_M, int WAVES_N, int MT, int NT, int BK, bool DEEP, bool STAMP = false>
+__global__ __launch_bounds__(256, (MT * NT == 4) ? (BK == 16 ? 3 : 2) : 1) void conv_gemm_kernel(const ConvGemmParams P) {
     constexpr int LDK = BK + 4;
     constexpr int BM = WAVES_M * MT * 32;
     constexpr int BN = WAVES_N * NT * 32;
@@ -111,8 +112,10 @@ __global__ __launch_bounds__(256, (BK == 16 && MT * NT == 4) ? 3 : 1) void conv_
         kw = tap - kh * P.KW;
     }
 
-    float4 ra[A_LD], rb[B_LD];
-    auto load_chunk = [&]() {
+    // Two register sets: chunk c+1 is written to LDS at the end of chunk c while chunk c+2 is already in
+    // flight (DEEP) -- global latency has two full MFMA phases (>= 8k cycles) to hide in.
+    float4 ra0[A_LD], rb0[B_LD], ra1[DEEP ? A_LD : 1], rb1[DEEP ? B_LD : 1];
+    auto load_chunk = [&](float4 (&ra)[A_LD], float4 (&rb)[B_LD]) {
         const bool kv = kglob < P.K;
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(256, (BK == 16 && MT * NT == 4) ? 3 : 1) void conv_
             if (++kw == P.KW) { kw = 0; ++kh; }
         }
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int buf, const float4 (&ra)[A_LD], const float4 (&rb)[B_LD]) {
         float *a = As + buf * BM * LDK;
         float *b = Bs + buf * BN * LDK;
 #pragma unroll
@@ -156,39 +159,83 @@ __global__ __launch_bounds__(256, (BK == 16 && MT * NT == 4) ? 3 : 1) void conv_
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nchunks = (P.K + BK - 1) / BK;
-    load_chunk();
-    store_chunk(0);
-    __syncthreads();
-
     const int frag_row = lane & 31;
     const int frag_k = 4 * (lane >> 5);
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunks) {
-            advance_k();
-            load_chunk();  // global loads in flight while the matrix pipe works on chunk c
-        }
+    auto compute = [&](int buf) {
         const float *a = As + buf * BM * LDK + (wm * MT * 32 + frag_row) * LDK + frag_k;
         const float *b = Bs + buf * BN * LDK + (wn * NT * 32 + frag_row) * LDK + frag_k;
+        // fragment registers are double-buffered: the ds_reads of k-group g+1 are issued before the MFMAs
+        // of group g, so LDS latency never sits between two MFMA groups
+        float4 fa[2][MT], fb[2][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[0][i] = *reinterpret_cast<const float4 *>(a + i * 32 * LDK);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[0][j] = *reinterpret_cast<const float4 *>(b + j * 32 * LDK);
 #pragma unroll
         for (int k8 = 0; k8 < BK / 8; ++k8) {
-            float4 fa[MT], fb[NT];
+            const int cur = k8 & 1, nxt = cur ^ 1;
+            if (k8 + 1 < BK / 8) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const float4 *>(a + i * 32 * LDK + k8 * 8);
+                for (int i = 0; i < MT; ++i) fa[nxt][i] = *reinterpret_cast<const float4 *>(a + i * 32 * LDK + (k8 + 1) * 8);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const float4 *>(b + j * 32 * LDK + k8 * 8);
+                for (int j = 0; j < NT; ++j) fb[nxt][j] = *reinterpret_cast<const float4 *>(b + j * 32 * LDK + (k8 + 1) * 8);
+            }
             // round-robin over the MT*NT independent accumulators: consecutive MFMAs never depend on each other
 #define VQ2_MFMA_STEP(C)                                                                                         \
     _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NT; ++j)                 \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].C, fb[j].C, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].C, fb[cur][j].C, acc[i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(1);
             VQ2_MFMA_STEP(x) VQ2_MFMA_STEP(y) VQ2_MFMA_STEP(z) VQ2_MFMA_STEP(w)
             __builtin_amdgcn_s_setprio(0);
 #undef VQ2_MFMA_STEP
         }
-        if (c + 1 < nchunks) store_chunk(buf ^ 1);
-        __syncthreads();
+    };
+
+    const int nchunks = (P.K + BK - 1) / BK;
+    load_chunk(ra0, rb0);
+    store_chunk(0, ra0, rb0);
+    __syncthreads();
+    if constexpr (!DEEP) {
+        unsigned long long t_load = 0, t_mfma = 0, t_store = 0, t_bar = 0;
+        for (int c = 0; c < nchunks; ++c) {
+            const int buf = c & 1;
+            unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            if constexpr (STAMP) s0 = __builtin_amdgcn_s_memtime();
+            if (c + 1 < nchunks) {
+                advance_k();
+                load_chunk(ra0, rb0);  // global loads in flight while the matrix pipe works on chunk c
+            }
+            if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); s1 = __builtin_amdgcn_s_memtime(); }
+            compute(buf);
+            if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); s2 = __builtin_amdgcn_s_memtime(); }
+            if (c + 1 < nchunks) store_chunk(buf ^ 1, ra0, rb0);
+            if constexpr (STAMP) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); s3 = __builtin_amdgcn_s_memtime(); }
+            __syncthreads();
+            if constexpr (STAMP) {
+                const unsigned long long s4 = __builtin_amdgcn_s_memtime();
+                t_load += s1 - s0; t_mfma += s2 - s1; t_store += s3 - s2; t_bar += s4 - s3;
+            }
+        }
+        if constexpr (STAMP) {
+            if (P.stamps && blockIdx.x == 64 && lane == 0) {
+                P.stamps[wave * 4 + 0] = t_load; P.stamps[wave * 4 + 1] = t_mfma;
+                P.stamps[wave * 4 + 2] = t_store; P.stamps[wave * 4 + 3] = t_bar;
+            }
+        }
+    } else {
+        // invariant at the top of an (even) iteration c: LDS[c&1] = chunk c, set0 = chunk c+1 (in flight)
+        if (nchunks > 1) { advance_k(); load_chunk(ra0, rb0); }
+        for (int c = 0; c < nchunks; c += 2) {
+            if (c + 2 < nchunks) { advance_k(); load_chunk(ra1, rb1); }       // chunk c+2
+            compute(0);
+            if (c + 1 < nchunks) store_chunk(1, ra0, rb0);                    // chunk c+1 -> LDS[1]
+            __syncthreads();
+            if (c + 1 >= nchunks) break;
+            if (c + 3 < nchunks) { advance_k(); load_chunk(ra0, rb0); }       // chunk c+3
+            compute(1);
+            if (c + 2 < nchunks) store_chunk(0, ra1, rb1);                    // chunk c+2 -> LDS[0]
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: lane holds column (lane&31) of 16 rows per 32x32 tile.
@@ -248,11 +295,278 @@ __global__ __launch_bounds__(256, (BK == 16 && MT * NT == 4) ? 3 : 1) void conv_
     }
 }
 
+
+// ====================================================================== low-VALU variant of the kernel
+// Cycle stamps (scripts/stamp_conv.py) showed that with two waves per SIMD the partner's fp32 MFMAs
+// starve a wave's vector ALU: the ~200 address/bounds instructions per chunk of the kernel above stretch
+// from ~1.0k to ~4.8k cycles, and the LDS-store/barrier phases end up unhidden.  This variant does the
+// same math with ~1/5 of the VALU work:
+//   * operands are fetched with raw BUFFER loads: 32-bit byte offsets, out-of-range lanes get a poisoned
+//     offset and the hardware range check returns zeros (no exec-mask branches, no 64-bit address math)
+//   * per row: base offset + a row mask and a column mask of in-bounds taps, computed once
+//   * per chunk: (tap, ci) advance without loops, tap offset from a small LDS table
+//   * epilogue: 32-bit offsets, one add per element; sub-pixel phases share one division per tile row
+// Limits (checked by the launcher): KH*KW <= 32, every tensor < 2 GiB.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int OOB = 0x7FFFFFF0;  // >= num_records of every descriptor: loads return 0, stores are dropped
+constexpr unsigned RSRC_FLAGS = 0x00020000;
+
+__device__ __forceinline__ float4 as_f4(u32x4 v) {
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 template <int WAVES_M, int WAVES_N, int MT, int NT, int BK>
+__global__ __launch_bounds__(256, (MT * NT == 4) ? 2 : 1) void conv_gemm_fast_kernel(const ConvGemmParams P) {
+    constexpr int LDK = BK + 4;
+    constexpr int BM = WAVES_M * MT * 32;
+    constexpr int BN = WAVES_N * NT * 32;
+    constexpr int KQ = BK / 4;
+    constexpr int RPP = 256 / KQ;
+    constexpr int A_LD = BM / RPP;
+    constexpr int B_LD = (BN + RPP - 1) / RPP;
+    static_assert(BM % RPP == 0 && (BN % RPP == 0 || BN < RPP), "tile vs staging shape");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;
+    float *Bs = smem + 2 * BM * LDK;
+    int *tap_off = reinterpret_cast<int *>(smem + 2 * (BM + BN) * LDK);  // [32] byte offset of tap (kh,kw)
+    int *tap_khw = tap_off + 32;                                        // [32] kh | kw << 8
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int ntiles = (P.Co + BN - 1) / BN;
+    const int mtiles = (P.M + BM - 1) / BM;
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = (vid % ntiles) * BN;
+    const int m0 = ((vid / ntiles) % mtiles) * BM;
+    const int phase = vid / (ntiles * mtiles);
+    int pad_h = P.pad_h, pad_w = P.pad_w, oh = 0, ow = 0, os = 1;
+    const float *wp = P.w;
+    if (P.phases == 4) {
+        const int ph = phase >> 1, pw = phase & 1;
+        pad_h = 1 - ph; pad_w = 1 - pw; oh = ph; ow = pw; os = 2;
+        wp += (size_t)phase * P.Co * P.K;
+    }
+    const int ntaps = P.KH * P.KW;
+    if (tid < ntaps) {
+        const int kh = tid / P.KW, kw = tid - kh * P.KW;
+        tap_off[tid] = (kh * P.W + kw) * P.ldx * 4;
+        tap_khw[tid] = kh | (kw << 8);
+    }
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x), 0, P.N * P.H * P.W * P.ldx * 4, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wp), 0, P.Co * P.K * 4, RSRC_FLAGS);
+
+    // ---- per-thread staging coordinates
+    const int lrow = tid / KQ;
+    const int lk = (tid % KQ) * 4;
+    const int HoWo = P.Ho * P.Wo;
+    int a_base[A_LD];
+    unsigned a_hm[A_LD], a_wm[A_LD];
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+        const int m = m0 + lrow + RPP * j;
+        a_base[j] = 0; a_hm[j] = 0; a_wm[j] = 0;
+        if (m < P.M) {
+            const int n = m / HoWo;
+            const int r = m - n * HoWo;
+            const int ho = r / P.Wo;
+            const int wo = r - ho * P.Wo;
+            const int hb = ho * P.stride - pad_h, wb = wo * P.stride - pad_w;
+            a_base[j] = ((n * P.H + hb) * P.W + wb) * P.ldx * 4;
+            for (int q = 0; q < P.KH; ++q) a_hm[j] |= ((unsigned)(hb + q) < (unsigned)P.H ? 1u : 0u) << q;
+            for (int q = 0; q < P.KW; ++q) a_wm[j] |= ((unsigned)(wb + q) < (unsigned)P.W ? 1u : 0u) << q;
+        }
+    }
+    int b_base[B_LD];
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+        const int co = n0 + lrow + RPP * j;
+        b_base[j] = (co < P.Co && lrow + RPP * j < BN) ? co * P.K * 4 : -1;
+    }
+    int kglob = lk;
+    int tap = kglob / P.Ci;
+    int ci = kglob - tap * P.Ci;
+    const int tstep = BK / P.Ci, cstep = BK - tstep * P.Ci;
+    __syncthreads();  // tap table visible
+
+    u32x4 ra[A_LD], rb[B_LD];
+    auto load_chunk = [&]() {
+        const bool kv = tap < ntaps;
+        const int tsel = kv ? tap : 0;
+        const int koff = tap_off[tsel] + ci * 4;
+        const int khw = tap_khw[tsel];
+        const int kh = khw & 255, kw = khw >> 8;
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            const bool v = kv && (((a_hm[j] >> kh) & (a_wm[j] >> kw) & 1u) != 0u);
+            ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, v ? a_base[j] + koff : OOB, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j)
+            rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (kv && b_base[j] >= 0) ? b_base[j] + kglob * 4 : OOB, 0, 0);
+    };
+    auto advance_k = [&]() {
+        kglob += BK;
+        ci += cstep;
+        tap += tstep;
+        if (ci >= P.Ci) { ci -= P.Ci; ++tap; }
+    };
+    auto store_chunk = [&](int buf) {
+        float *a = As + buf * BM * LDK;
+        float *b = Bs + buf * BN * LDK;
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            const float4 v = as_f4(ra[j]);
+            *reinterpret_cast<float4 *>(a + (lrow + RPP * j) * LDK + lk) = P.relu_in ? relu4(v) : v;
+        }
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j)
+            if (BN % RPP == 0 || lrow + RPP * j < BN) *reinterpret_cast<float4 *>(b + (lrow + RPP * j) * LDK + lk) = as_f4(rb[j]);
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frag_row = lane & 31;
+    const int frag_k = 4 * (lane >> 5);
+    auto compute = [&](int buf) {
+        const float *a = As + buf * BM * LDK + (wm * MT * 32 + frag_row) * LDK + frag_k;
+        const float *b = Bs + buf * BN * LDK + (wn * NT * 32 + frag_row) * LDK + frag_k;
+        float4 fa[2][MT], fb[2][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[0][i] = *reinterpret_cast<const float4 *>(a + i * 32 * LDK);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[0][j] = *reinterpret_cast<const float4 *>(b + j * 32 * LDK);
+#pragma unroll
+        for (int k8 = 0; k8 < BK / 8; ++k8) {
+            const int cur = k8 & 1, nxt = cur ^ 1;
+            if (k8 + 1 < BK / 8) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) fa[nxt][i] = *reinterpret_cast<const float4 *>(a + i * 32 * LDK + (k8 + 1) * 8);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) fb[nxt][j] = *reinterpret_cast<const float4 *>(b + j * 32 * LDK + (k8 + 1) * 8);
+            }
+#define VQ2_MFMA_STEP(C)                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NT; ++j)                 \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].C, fb[cur][j].C, acc[i][j], 0, 0, 0);
+            VQ2_MFMA_STEP(x) VQ2_MFMA_STEP(y) VQ2_MFMA_STEP(z) VQ2_MFMA_STEP(w)
+#undef VQ2_MFMA_STEP
+        }
+    };
+
+    const int nchunks = (P.K + BK - 1) / BK;
+    load_chunk();
+    store_chunk(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) {
+            advance_k();
+            load_chunk();
+        }
+        compute(buf);
+        if (c + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue with 32-bit offsets through buffer descriptors
+    const int ybytes = P.N * P.Hy * P.Wy * 4;  // per unit of pixel stride
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(P.y, 0, ybytes * P.ldy, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rmk =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.mask ? P.mask : P.y), 0, P.mask ? ybytes * P.ldm : 0, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.res ? P.res : P.y), 0, P.res ? ybytes * P.ldr : 0, RSRC_FLAGS);
+    const bool has_mask = P.mask != nullptr, has_res = P.res != nullptr;
+    const int colq = lane & 31;
+    const int rowq = 4 * (lane >> 5);
+    const int ldy4 = P.ldy * 4, ldm4 = P.ldm * 4, ldr4 = P.ldr * 4;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int mt0 = m0 + (wm * MT + i) * 32;   // first GEMM row of this 32-row tile
+        // pixel index of row (lane & 31) of the tile: identity for a dense grid, one decomposition per
+        // lane (shared through ds_bpermute) for the strided sub-pixel phases
+        int pix_lane;
+        {
+            const int m = mt0 + colq;
+            if (os == 1) {
+                pix_lane = m;
+            } else {
+                const int n = m / HoWo;
+                const int rr = m - n * HoWo;
+                const int ho = rr / P.Wo;
+                const int wo = rr - ho * P.Wo;
+                pix_lane = (n * P.Hy + (ho * 2 + oh)) * P.Wy + (wo * 2 + ow);
+            }
+            if (m >= P.M) pix_lane = -1;
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int co = n0 + (wn * NT + j) * 32 + colq;
+            const bool cv = co < P.Co;
+            const float bv = (P.bias && co < P.nbias) ? P.bias[co] : 0.f;
+            const int co4 = co * 4;
+#pragma unroll
+            for (int rb8 = 0; rb8 < 16; rb8 += 8) {
+                int pix[8];
+                float mk[8], rs[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = rb8 + q;
+                    const int rr = rowq + (r & 3) + 8 * (r >> 2);
+                    pix[q] = (os == 1) ? ((mt0 + rr < P.M) ? mt0 + rr : -1) : __shfl(pix_lane, rr, 64);
+                    if (!cv) pix[q] = -1;
+                }
+                if (has_mask) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        mk[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rmk, pix[q] >= 0 ? pix[q] * ldm4 + co4 : OOB, 0, 0));
+                }
+                if (has_res) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        rs[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, pix[q] >= 0 ? pix[q] * ldr4 + co4 : OOB, 0, 0));
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float v = acc[i][j][rb8 + q] + bv;
+                    if (has_mask) v = (mk[q] > 0.f) ? v : 0.f;
+                    if (has_res) v += rs[q];
+                    if (P.relu_out) v = fmaxf(v, 0.f);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, pix[q] >= 0 ? pix[q] * ldy4 + co4 : OOB, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+template <int WAVES_M, int WAVES_N, int MT, int NT, int BK>
+static int launch_conv_gemm_fast(const ConvGemmParams &P, hipStream_t s) {
+    constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
+    const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float) + 64 * sizeof(int);
+    auto kern = conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK>;
+    allow_big_lds(kern, lds);
+    dim3 grid(((P.M + BM - 1) / BM) * ((P.Co + BN - 1) / BN) * P.phases);
+    const char *name = "conv_gemm";
+    if (prof_enabled())
+        name = prof_label("conv_gemm<%dx%dx%d>|M=%d,N=%d,K=%d,k%d,s%d,ph%d", BM, BN, BK, P.M, P.Co, P.K, P.KH, P.stride,
+                          P.phases);
+    ProfScope prof(name, P.flops, P.bytes, s, BM == 128 && BN == 128 && BK == 32);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, P);
+    return check_launch("conv_gemm_fast_kernel");
+}
+
+template <int WAVES_M, int WAVES_N, int MT, int NT, int BK, bool DEEP = false, bool STAMP = false>
 static int launch_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
     constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
-    const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
-    auto kern = conv_gemm_kernel<WAVES_M, WAVES_N, MT, NT, BK>;
+    static const int lds_pad = getenv("VQ2_LDS_PAD") ? atoi(getenv("VQ2_LDS_PAD")) : 0;  // experiments: force 1 WG/CU
+    const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float) + lds_pad;
+    auto kern = conv_gemm_kernel<WAVES_M, WAVES_N, MT, NT, BK, DEEP, STAMP>;
     allow_big_lds(kern, lds);
     dim3 grid(((P.M + BM - 1) / BM) * ((P.Co + BN - 1) / BN) * P.phases);
     const char *name = "conv_gemm";
@@ -263,6 +577,8 @@ static int launch_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, P);
     return check_launch("conv_gemm_kernel");
 }
+
+static unsigned long long *g_stamps = nullptr;  // set by vq2_debug_set_stamps: diagnostic cycle stamps
 
 static int tune(const char *name, int dflt) {
     const char *v = getenv(name);
@@ -277,12 +593,29 @@ static int run_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
     // few row tiles (the 32x32-resolution layers): halve the tile height so every CU still holds >= 2
     // workgroups and the matrix pipe of a SIMD always has a second wave to switch to
     const long wgs128 = (long)((P.M + 127) / 128) * ((P.Co + 127) / 128) * P.phases;
+    static const int fast = tune("VQ2_FAST", 1);
+    const long lim = (1L << 29);  // elements: every tensor below 2 GiB so that 32-bit byte offsets suffice
+    const bool fast_ok = fast && P.KH * P.KW <= 32 && (long)P.N * P.H * P.W * P.ldx < lim &&
+                         (long)P.N * P.Hy * P.Wy * P.ldy < lim && (long)P.N * P.Hy * P.Wy * (P.ldm > P.ldr ? P.ldm : P.ldr) < lim &&
+                         (long)P.Co * P.K * P.phases < lim;
+    if (fast_ok && !g_stamps) {
+        if (small_m && wgs128 < 400 && P.Co > 32) {
+            if (P.Co > 64) return launch_conv_gemm_fast<2, 2, 1, 2, 16>(P, s);
+            return launch_conv_gemm_fast<2, 2, 1, 1, 16>(P, s);
+        }
+        if (P.Co > 64) return launch_conv_gemm_fast<2, 2, 2, 2, 32>(P, s);
+        if (P.Co > 32) return launch_conv_gemm_fast<2, 2, 2, 1, 16>(P, s);
+        return launch_conv_gemm_fast<4, 1, 1, 1, 16>(P, s);
+    }
     if (small_m && wgs128 < 400 && P.Co > 32) {
         if (P.Co > 64) return launch_conv_gemm<2, 2, 1, 2, 16>(P, s);      // 64 x 128
         return launch_conv_gemm<2, 2, 1, 1, 16>(P, s);                     // 64 x 64
     }
     if (P.Co > 64) {
+        static const int deep = tune("VQ2_DEEP", 0);
         if (bk128 == 16) return launch_conv_gemm<2, 2, 2, 2, 16>(P, s);
+        if (deep) return launch_conv_gemm<2, 2, 2, 2, 32, true>(P, s);     // 128 x 128, 2-deep register prefetch
+        if (g_stamps) { ConvGemmParams Q = P; Q.stamps = g_stamps; return launch_conv_gemm<2, 2, 2, 2, 32, false, true>(Q, s); }
         return launch_conv_gemm<2, 2, 2, 2, 32>(P, s);                     // 128 x 128
     }
     if (P.Co > 32) {
@@ -588,4 +921,11 @@ extern "C" int vq2_conv_dgrad(const vq2_conv_desc *d, const float *dy, const flo
                          cir * cor * d->KH * d->KW);
     }
     return run_conv_gemm(P, to_stream(stream));
+}
+
+// diagnostic only: when set, the 128x128x32 conv tile runs its STAMP build and workgroup 64 writes, per
+// wave, the summed s_memtime cycles of {load issue, MFMA phase, LDS store, barrier} to buf[16]
+extern "C" int vq2_debug_set_stamps(unsigned long long *buf) {
+    g_stamps = buf;
+    return VQ2_OK;
 }

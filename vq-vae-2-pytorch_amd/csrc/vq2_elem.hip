@@ -268,3 +268,35 @@ extern "C" int vq2_scale(const float *src, const float *scalar, float alpha, flo
     hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(256), 0, to_stream(stream), src, scalar, alpha, dst, n);
     return check_launch("scale_kernel");
 }
+
+// ------------------------------------------------------------------ calibration (not on the product path)
+// Register-resident v_mfma_f32_32x32x2_f32 loop: what the chip sustains for this instruction at the
+// clock it holds under load -- the practical ceiling the conv kernels are measured against in DESIGN.md.
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float *out, int iters, float seed) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float a = seed + threadIdx.x * 1e-3f, b = seed - threadIdx.x * 2e-3f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+            a += 1e-6f;
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 123.456f) out[0] = s;  // keep the loop alive
+}
+
+extern "C" int vq2_debug_mfma_peak(float *scratch, int32_t blocks, int32_t iters, vq2_stream_t stream) {
+    VQ2_REQUIRE(scratch && blocks > 0 && iters > 0, "mfma_peak: bad arguments");
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, to_stream(stream), scratch, iters, 0.5f);
+    return check_launch("mfma_peak_kernel");
+}
