@@ -13,6 +13,7 @@
 // from NHWC memory: v_mfma_f32_32x32x2_f32 wants A[i][k] / B[k][j] with lanes along i / j,
 // and consecutive lanes read consecutive channels -> conflict-free ds_read_b32, no transposes.
 #include "vq2_common.h"
+#include <stdlib.h>
 
 namespace vq2 {
 
@@ -188,6 +189,185 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
     }
 }
 
+// ====================================================================== low-VALU variant
+// Same math as wgrad_kernel for the common case Wo % 32 == 0: a 32-row chunk then lies inside ONE output
+// row, so (n, ho, wo0) of the chunk is wave-uniform and tracked on the scalar unit; every gather offset
+// is "uniform chunk base + per-thread constant" -- one vector add per load, fetched with raw buffer loads
+// whose range check supplies the zeros (no exec branches, no 64-bit address math).  With two waves per
+// SIMD the partner's fp32 MFMAs starve the vector ALU, so the address work is what was limiting.
+typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
+constexpr int WOOB = 0x7FFFFFF0;
+constexpr unsigned WRSRC_FLAGS = 0x00020000;
+
+__device__ __forceinline__ float4 as_f4w(u32x4w v) {
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+template <int WAVES_M, int WAVES_N, int MT, int NT>
+__global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
+    constexpr int BMO = WAVES_M * MT * 32;
+    constexpr int BNK = WAVES_N * NT * 32;
+    constexpr int G_C4 = BMO / 4, X_C4 = BNK / 4;
+    constexpr int G_RSTEP = 256 / G_C4, X_RSTEP = 256 / X_C4;
+    constexpr int G_LD = WG_BKR / G_RSTEP, X_LD = WG_BKR / X_RSTEP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Gs = smem;
+    float *Xs = smem + 2 * WG_BKR * BMO;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int ktiles = (P.K + BNK - 1) / BNK;
+    const int otiles = (P.O + BMO - 1) / BMO;
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int k0 = (vid % ktiles) * BNK;
+    const int o0 = ((vid / ktiles) % otiles) * BMO;
+    const int split = vid / (ktiles * otiles);
+    const int m_begin = split * P.rows_per_split;
+    const int m_end = min(P.M, m_begin + P.rows_per_split);
+
+    const __amdgpu_buffer_rsrc_t rg =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.g), 0, P.M * P.ldg * 4, WRSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x), 0, P.N * P.H * P.W * P.ldx * 4, WRSRC_FLAGS);
+
+    // per-thread constants
+    const int g_c = o0 + (tid % G_C4) * 4;
+    const int g_r = tid / G_C4;
+    const int x_k = k0 + (tid % X_C4) * 4;
+    const int x_r = tid / X_C4;
+    const bool g_cv = g_c < P.O;
+    const bool x_kv = x_k < P.K;
+    int kh = 0, kw = 0, ci = 0;
+    if (x_kv) {
+        const int tap = x_k / P.I;
+        ci = x_k - tap * P.I;
+        kh = tap / P.KW;
+        kw = tap - kh * P.KW;
+    }
+    int g_const[G_LD], x_const[X_LD], x_iw[X_LD];
+#pragma unroll
+    for (int j = 0; j < G_LD; ++j) g_const[j] = ((g_r + j * G_RSTEP) * P.ldg + g_c) * 4;
+#pragma unroll
+    for (int j = 0; j < X_LD; ++j) {
+        const int rj = x_r + j * X_RSTEP;                    // row inside the 32-row chunk
+        x_iw[j] = rj * P.stride - P.pad + kw;                // + wo0*stride = input column
+        x_const[j] = ((kh * P.W + kw + rj * P.stride) * P.ldx + ci) * 4;
+    }
+    // wave-uniform chunk position (scalar registers)
+    int un, uho, uwo;
+    {
+        const int HoWo = P.Ho * P.Wo;
+        un = m_begin / HoWo;
+        const int r = m_begin - un * HoWo;
+        uho = r / P.Wo;
+        uwo = r - uho * P.Wo;
+    }
+
+    u32x4w rgv[G_LD], rxv[X_LD];
+    auto load_chunk = [&](int mbase) {
+        const int rows_left = m_end - mbase;                  // uniform
+        const int gbase = mbase * P.ldg * 4;                  // uniform
+#pragma unroll
+        for (int j = 0; j < G_LD; ++j) {
+            const bool v = g_cv && (g_r + j * G_RSTEP) < rows_left;
+            rgv[j] = __builtin_amdgcn_raw_buffer_load_b128(rg, v ? gbase + g_const[j] : WOOB, 0, 0);
+        }
+        const int ihu = uho * P.stride - P.pad;               // uniform
+        const int xbase = ((un * P.H + ihu) * P.W + uwo * P.stride - P.pad) * P.ldx * 4;  // uniform
+        const bool hv = x_kv && (unsigned)(ihu + kh) < (unsigned)P.H;
+        const int iwu = uwo * P.stride;
+#pragma unroll
+        for (int j = 0; j < X_LD; ++j) {
+            const bool v = hv && (x_r + j * X_RSTEP) < rows_left && (unsigned)(iwu + x_iw[j]) < (unsigned)P.W;
+            rxv[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, v ? xbase + x_const[j] : WOOB, 0, 0);
+        }
+        // next chunk: 32 rows further along the same output row, or the start of the next one
+        uwo += WG_BKR;
+        if (uwo >= P.Wo) {
+            uwo = 0;
+            if (++uho == P.Ho) { uho = 0; ++un; }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        float *gs = Gs + buf * WG_BKR * BMO;
+        float *xs = Xs + buf * WG_BKR * BNK;
+#pragma unroll
+        for (int j = 0; j < G_LD; ++j) {
+            const float4 v = as_f4w(rgv[j]);
+            *reinterpret_cast<float4 *>(gs + (g_r + j * G_RSTEP) * BMO + (tid % G_C4) * 4) = P.relu_g ? relu4(v) : v;
+        }
+#pragma unroll
+        for (int j = 0; j < X_LD; ++j) {
+            const float4 v = as_f4w(rxv[j]);
+            *reinterpret_cast<float4 *>(xs + (x_r + j * X_RSTEP) * BNK + (tid % X_C4) * 4) = P.relu_x ? relu4(v) : v;
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nchunks = (m_end - m_begin + WG_BKR - 1) / WG_BKR;
+    if (nchunks > 0) {
+        load_chunk(m_begin);
+        store_chunk(0);
+    }
+    __syncthreads();
+    const int fr = lane & 31, fk = lane >> 5;
+    const bool do_bias = P.bias_ws != nullptr && k0 == 0 && tid < BMO;
+    float bsum = 0.f;
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) load_chunk(m_begin + (c + 1) * WG_BKR);
+        if (do_bias) {
+            const float *gcol = Gs + buf * WG_BKR * BMO + tid;
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < WG_BKR; r += 2) { s0 += gcol[r * BMO]; s1 += gcol[(r + 1) * BMO]; }
+            bsum += s0 + s1;
+        }
+        const float *gs = Gs + buf * WG_BKR * BMO + fk * BMO + wm * MT * 32 + fr;
+        const float *xs = Xs + buf * WG_BKR * BNK + fk * BNK + wn * NT * 32 + fr;
+#pragma unroll
+        for (int kk = 0; kk < WG_BKR / 2; ++kk) {
+            float fa[MT], fb[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[i] = gs[kk * 2 * BMO + i * 32];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[j] = xs[kk * 2 * BNK + j * 32];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (c + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+    if (do_bias && o0 + tid < P.O) P.bias_ws[(size_t)split * P.O + o0 + tid] = bsum;
+
+    float *slab = P.ws + (size_t)split * P.O * P.K;
+    const int colq = lane & 31, rowq = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int k = k0 + (wn * NT + j) * 32 + colq;
+        if (k >= P.K) continue;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int ob = o0 + (wm * MT + i) * 32 + rowq;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = ob + (r & 3) + 8 * (r >> 2);
+                if (o < P.O) slab[(size_t)o * P.K + k] = acc[i][j][r];
+            }
+        }
+    }
+}
+
 // Sum the slabs and scatter [o][tap][i] (padded O x I) -> reference layout [Or][Ir][tap].
 // 256 threads = 32 outputs x 8 split-lanes: lane g adds splits g, g+8, ... (4 loads in flight), the 8
 // partial sums are combined through LDS in a fixed order -> bit-reproducible, and latency is paid
@@ -338,7 +518,11 @@ template <int WAVES_M, int WAVES_N, int MT, int NT>
 static int launch_wgrad(const WgradParams &P, int S, hipStream_t s) {
     constexpr int BMO = WAVES_M * MT * 32, BNK = WAVES_N * NT * 32;
     const size_t lds = (size_t)2 * WG_BKR * (BMO + BNK) * sizeof(float);
-    auto kern = wgrad_kernel<WAVES_M, WAVES_N, MT, NT>;
+    static const int fast = getenv("VQ2_WFAST") ? atoi(getenv("VQ2_WFAST")) : 1;
+    const long lim = 1L << 29;
+    const bool fast_ok = fast && P.Wo % WG_BKR == 0 && P.rows_per_split % WG_BKR == 0 &&
+                         (long)P.N * P.H * P.W * P.ldx < lim && (long)P.M * P.ldg < lim;
+    auto kern = fast_ok ? wgrad_fast_kernel<WAVES_M, WAVES_N, MT, NT> : wgrad_kernel<WAVES_M, WAVES_N, MT, NT>;
     allow_big_lds(kern, lds);
     dim3 grid(((P.K + BNK - 1) / BNK) * ((P.O + BMO - 1) / BMO) * S);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, P);
