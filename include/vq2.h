@@ -175,7 +175,8 @@ int vq2_vq_bwd(const float *g_out, int32_t ldg, const float *g_diff, const float
                const int64_t *idx, const float *embedT, int64_t M, int32_t D, int32_t K, float *dx, int32_t lddx,
                vq2_stream_t stream);
 int vq2_vq_ema_update(float *embed, float *cluster_size, float *embed_avg, const float *counts, const float *sumsT,
-                      int32_t D, int32_t K, double decay, double eps, vq2_stream_t stream);
+                      int32_t D, int32_t K, double decay, double eps, float *scratch /* >= 1 float */,
+                      vq2_stream_t stream);
 int vq2_vq_gather(const int64_t *idx, const float *embedT, int64_t M, int32_t D, int32_t K, float *out, int32_t ldo,
                   vq2_stream_t stream);
 

@@ -61,7 +61,7 @@ def _load():
         "vq2_vq_fwd": (C.c_int, [P, I32, P, P, P, I64, I32, I32, P, P, I32, P, P, P, P]),
         "vq2_vq_loss": (C.c_int, [P, I64, I32, P, P]),
         "vq2_vq_bwd": (C.c_int, [P, I32, P, P, I32, P, P, I64, I32, I32, P, I32, P]),
-        "vq2_vq_ema_update": (C.c_int, [P, P, P, P, P, I32, I32, D, D, P]),
+        "vq2_vq_ema_update": (C.c_int, [P, P, P, P, P, I32, I32, D, D, P, P]),
         "vq2_vq_gather": (C.c_int, [P, P, I64, I32, I32, P, I32, P]),
         "vq2_mse_workspace_bytes": (SZ, [I64]),
         "vq2_mse_fwd_bwd": (C.c_int, [P, P, I64, I64, P, P, P, P, SZ, P]),

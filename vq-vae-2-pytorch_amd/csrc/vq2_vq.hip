@@ -184,17 +184,23 @@ __global__ __launch_bounds__(256) void vq_hist_kernel(const int64_t *__restrict_
         if (hist[k]) atomicAdd(counts + k, (float)hist[k]);
 }
 
-__global__ void vq_prepare_kernel(const float *__restrict__ embed, float *__restrict__ embedT,
-                                  float *__restrict__ enorm, int D, int K) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K) return;
+// embedT[k][d] = embed[d][k], enorm[k] = sum_d embed[d][k]^2: 64 codes x 4 d-lanes per workgroup
+__global__ __launch_bounds__(256) void vq_prepare_kernel(const float *__restrict__ embed, float *__restrict__ embedT,
+                                                         float *__restrict__ enorm, int D, int K) {
+    __shared__ float part[4][64];
+    const int kq = threadIdx.x & 63, dg = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + kq;
     float s = 0.f;
-    for (int d = 0; d < D; ++d) {
-        const float e = embed[(size_t)d * K + k];
-        embedT[(size_t)k * D + d] = e;
-        s += e * e;
+    if (k < K) {
+        for (int d = dg; d < D; d += 4) {
+            const float e = embed[(size_t)d * K + k];
+            embedT[(size_t)k * D + d] = e;
+            s += e * e;
+        }
     }
-    enorm[k] = s;
+    part[dg][kq] = s;
+    __syncthreads();
+    if (dg == 0 && k < K) enorm[k] = (part[0][kq] + part[1][kq]) + (part[2][kq] + part[3][kq]);
 }
 
 __global__ void vq_loss_kernel(const float *__restrict__ part, int nparts, float denom, float *__restrict__ diff) {
@@ -234,11 +240,10 @@ __global__ void vq_bwd_kernel(const float *__restrict__ g_out, int ldg, const fl
     }
 }
 
-// vqvae.py:61-70, one workgroup: the Laplace-smoothing total n depends on every updated count
-__global__ __launch_bounds__(1024) void vq_ema_kernel(float *__restrict__ embed, float *__restrict__ cluster_size,
-                                                      float *__restrict__ embed_avg, const float *__restrict__ counts,
-                                                      const float *__restrict__ sumsT, int D, int K, float decay,
-                                                      float alpha, float eps, float keps) {
+// vqvae.py:61-66: cluster_size EMA and its total n (one workgroup; n feeds the Laplace smoothing)
+__global__ __launch_bounds__(1024) void vq_ema_counts_kernel(float *__restrict__ cluster_size,
+                                                             const float *__restrict__ counts, int K, float decay,
+                                                             float alpha, float *__restrict__ n_out) {
     __shared__ float red[1024];
     float local = 0.f;
     for (int k = threadIdx.x; k < K; k += 1024) {
@@ -252,15 +257,25 @@ __global__ __launch_bounds__(1024) void vq_ema_kernel(float *__restrict__ embed,
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    const float n = red[0];
+    if (threadIdx.x == 0) n_out[0] = red[0];
+}
+
+// vqvae.py:64, 67-70: embed_avg EMA and the normalised codebook; thread index runs over [k][d] so the
+// transposed statistics are read coalesced
+__global__ __launch_bounds__(256) void vq_ema_embed_kernel(float *__restrict__ embed, const float *__restrict__ cluster_size,
+                                                           float *__restrict__ embed_avg, const float *__restrict__ sumsT,
+                                                           int D, int K, float decay, float alpha, float eps, float keps,
+                                                           const float *__restrict__ n_in) {
+    const float n = n_in[0];
     const float denom = n + keps;
     const int total = D * K;
-    for (int t = threadIdx.x; t < total; t += 1024) {
-        const int d = t / K, k = t - d * K;
-        const float ea = fmaf(alpha, sumsT[(size_t)k * D + d], embed_avg[t] * decay);
-        embed_avg[t] = ea;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+        const int k = t / D, d = t - k * D;
+        const size_t o = (size_t)d * K + k;
+        const float ea = fmaf(alpha, sumsT[t], embed_avg[o] * decay);
+        embed_avg[o] = ea;
         const float cs = (cluster_size[k] + eps) / denom * n;
-        embed[t] = ea / cs;
+        embed[o] = ea / cs;
     }
 }
 
@@ -289,7 +304,7 @@ using namespace vq2;
 extern "C" int vq2_vq_prepare(const float *embed, float *embedT, float *enorm, int32_t D, int32_t K,
                               vq2_stream_t stream) {
     VQ2_REQUIRE(embed && embedT && enorm && D > 0 && K > 0, "vq_prepare: bad arguments");
-    hipLaunchKernelGGL(vq_prepare_kernel, dim3((K + 255) / 256), dim3(256), 0, to_stream(stream), embed, embedT, enorm,
+    hipLaunchKernelGGL(vq_prepare_kernel, dim3((K + 63) / 64), dim3(256), 0, to_stream(stream), embed, embedT, enorm,
                        D, K);
     return check_launch("vq_prepare_kernel");
 }
@@ -348,14 +363,20 @@ extern "C" int vq2_vq_bwd(const float *g_out, int32_t ldg, const float *g_diff, 
 }
 
 extern "C" int vq2_vq_ema_update(float *embed, float *cluster_size, float *embed_avg, const float *counts,
-                                 const float *sumsT, int32_t D, int32_t K, double decay, double eps,
+                                 const float *sumsT, int32_t D, int32_t K, double decay, double eps, float *scratch,
                                  vq2_stream_t stream) {
-    VQ2_REQUIRE(embed && cluster_size && embed_avg && counts && sumsT && D > 0 && K > 0, "vq_ema_update: bad arguments");
+    VQ2_REQUIRE(embed && cluster_size && embed_avg && counts && sumsT && scratch && D > 0 && K > 0,
+                "vq_ema_update: bad arguments");
     // Python forms (1 - decay) and n_embed * eps in double before the fp32 ops (vqvae.py:62,67)
     const float alpha = (float)(1.0 - decay);
-    hipLaunchKernelGGL(vq_ema_kernel, dim3(1), dim3(1024), 0, to_stream(stream), embed, cluster_size, embed_avg, counts,
-                       sumsT, D, K, (float)decay, alpha, (float)eps, (float)((double)K * eps));
-    return check_launch("vq_ema_kernel");
+    hipStream_t s = to_stream(stream);
+    hipLaunchKernelGGL(vq_ema_counts_kernel, dim3(1), dim3(1024), 0, s, cluster_size, counts, K, (float)decay, alpha,
+                       scratch);
+    if (int e = check_launch("vq_ema_counts_kernel")) return e;
+    const int blocks = (D * K + 255) / 256;
+    hipLaunchKernelGGL(vq_ema_embed_kernel, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, s, embed, cluster_size,
+                       embed_avg, sumsT, D, K, (float)decay, alpha, (float)eps, (float)((double)K * eps), scratch);
+    return check_launch("vq_ema_embed_kernel");
 }
 
 extern "C" int vq2_vq_gather(const int64_t *idx, const float *embedT, int64_t M, int32_t D, int32_t K, float *out,

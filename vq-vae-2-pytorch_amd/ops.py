@@ -7,6 +7,7 @@ every FLOP and every byte moved on this path is a libvq2 kernel.
 """
 from dataclasses import dataclass
 import ctypes as C
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -128,6 +129,8 @@ def packed_weight(spec, weight, which):
     key = (id(weight), which)
     ver = (weight.data_ptr(), weight._version, WEIGHT_EPOCH[0], spec)
     hit = _pack_cache.get(key)
+    if hit is not None and (len(hit) < 3 or hit[2]() is not weight):
+        hit = None  # id() of a dead tensor was recycled: never trust that entry
     if hit is not None and hit[0] == ver:
         return hit[1]
     _require_cuda(weight, "weight")
@@ -139,7 +142,7 @@ def packed_weight(spec, weight, which):
                                                                                dtype=torch.float32)
     d = _desc(spec, 1, max(spec.k, 2), max(spec.k, 2), spec.ci, spec.co)
     check(lib.vq2_pack_weight(C.byref(d), which, _p(wsrc), _p(buf), _stream()), "pack_weight")
-    _pack_cache[key] = (ver, buf)
+    _pack_cache[key] = (ver, buf, weakref.ref(weight))
     return buf
 
 
@@ -183,7 +186,8 @@ class PackPlan:
             raise RuntimeError("PackPlan: a parameter was re-allocated; rebuild the plan")
         check(lib.vq2_pack_weights_batched(_p(self.jobs_dev), self.njobs, self.total, _stream()), "pack_batched")
         for spec, weight, which, buf in self.entries:
-            _pack_cache[(id(weight), which)] = ((weight.data_ptr(), weight._version, WEIGHT_EPOCH[0], spec), buf)
+            _pack_cache[(id(weight), which)] = ((weight.data_ptr(), weight._version, WEIGHT_EPOCH[0], spec), buf,
+                                                weakref.ref(weight))
 
 
 def conv_forward(spec, x, weight, bias, flags=0, residual=None, out=None):
@@ -603,8 +607,9 @@ class QuantizeFn(Function):
 def vq_ema_update(embed, cluster_size, embed_avg, stats, decay, eps):
     d, k = embed.shape
     counts, sums_t = stats[:k], stats[k:]
+    scratch = torch.empty(4, device=embed.device, dtype=torch.float32)
     check(lib.vq2_vq_ema_update(_p(embed), _p(cluster_size), _p(embed_avg), _p(counts), _p(sums_t), d, k,
-                                float(decay), float(eps), _stream()), "vq_ema_update")
+                                float(decay), float(eps), _p(scratch), _stream()), "vq_ema_update")
 
 
 def vq_gather(idx, embed):
