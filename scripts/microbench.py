@@ -20,6 +20,7 @@ CASES = {
     "t_128_64": (ConvSpec(True, 128, 64, 4, 2, 1), 32, 64, 64),
     "t_64_3": (ConvSpec(True, 64, 3, 4, 2, 1), 32, 128, 128),
     "c1_192_64": (ConvSpec(False, 192, 64, 1, 1, 0), 32, 64, 64),
+    "c3_32_128": (ConvSpec(False, 32, 128, 3, 1, 1), 32, 64, 64),   # shape of the ResBlock 3x3 data gradient
     # 32x32-resolution layers (enc_t / dec_t)
     "s_c3_64_128": (ConvSpec(False, 64, 128, 3, 1, 1), 32, 32, 32),
     "s_c3_128_32": (ConvSpec(False, 128, 32, 3, 1, 1), 32, 32, 32),

@@ -599,12 +599,28 @@ static int run_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
                          (long)P.N * P.Hy * P.Wy * P.ldy < lim && (long)P.N * P.Hy * P.Wy * (P.ldm > P.ldr ? P.ldm : P.ldr) < lim &&
                          (long)P.Co * P.K * P.phases < lim;
     if (fast_ok && !g_stamps) {
+        static const int t32 = tune("VQ2_T32", 1), tk = tune("VQ2_TSHORTK", 0), t64 = tune("VQ2_T64", 0),
+                         tsm = tune("VQ2_TSM", 1);
         if (small_m && wgs128 < 400 && P.Co > 32) {
-            if (P.Co > 64) return launch_conv_gemm_fast<2, 2, 1, 2, 16>(P, s);
+            if (P.Co > 64) {
+                if (tsm == 1) return launch_conv_gemm_fast<2, 2, 1, 2, 32>(P, s);
+                return launch_conv_gemm_fast<2, 2, 1, 2, 16>(P, s);
+            }
+            if (tsm == 1) return launch_conv_gemm_fast<2, 2, 1, 1, 32>(P, s);
             return launch_conv_gemm_fast<2, 2, 1, 1, 16>(P, s);
         }
-        if (P.Co > 64) return launch_conv_gemm_fast<2, 2, 2, 2, 32>(P, s);
-        if (P.Co > 32) return launch_conv_gemm_fast<2, 2, 2, 1, 16>(P, s);
+        if (P.Co > 64) {
+            if (tk == 1 && P.K <= 512) return launch_conv_gemm_fast<2, 2, 1, 2, 16>(P, s);   // 64 x 128 for short K
+            if (tk == 2 && P.K <= 512) return launch_conv_gemm_fast<2, 2, 1, 2, 32>(P, s);
+            return launch_conv_gemm_fast<2, 2, 2, 2, 32>(P, s);
+        }
+        if (P.Co > 32) {
+            if (t64 == 1) return launch_conv_gemm_fast<2, 2, 2, 1, 32>(P, s);
+            return launch_conv_gemm_fast<2, 2, 2, 1, 16>(P, s);
+        }
+        if (t32 == 1) return launch_conv_gemm_fast<4, 1, 1, 1, 32>(P, s);
+        if (t32 == 2) return launch_conv_gemm_fast<4, 1, 2, 1, 16>(P, s);
+        if (t32 == 3) return launch_conv_gemm_fast<4, 1, 2, 1, 32>(P, s);
         return launch_conv_gemm_fast<4, 1, 1, 1, 16>(P, s);
     }
     if (small_m && wgs128 < 400 && P.Co > 32) {
