@@ -253,8 +253,17 @@ class WgradBatch:
             ent = {"ws": ws, "nbytes": nbytes, "job": job, "dw": dw, "db": db, "used": False}
             self.entries[key] = ent
             self.dirty = True
-        check(lib.vq2_conv_wgrad_partial(C.byref(d), VQ2_RELU_IN if relu_in else 0, _p(x), _p(dy), _p(ent["db"]),
-                                         _p(ent["ws"]), ent["nbytes"], _stream()), "conv_wgrad_partial")
+        side = WGRAD_STREAM[0]
+        if side is not None:   # off the backward critical path: overlaps the next layers' data gradients
+            side.wait_event(torch.cuda.current_stream().record_event())
+            with torch.cuda.stream(side):
+                check(lib.vq2_conv_wgrad_partial(C.byref(d), VQ2_RELU_IN if relu_in else 0, _p(x), _p(dy), _p(ent["db"]),
+                                                 _p(ent["ws"]), ent["nbytes"], _stream()), "conv_wgrad_partial")
+            x.record_stream(side)
+            dy.record_stream(side)
+        else:
+            check(lib.vq2_conv_wgrad_partial(C.byref(d), VQ2_RELU_IN if relu_in else 0, _p(x), _p(dy), _p(ent["db"]),
+                                             _p(ent["ws"]), ent["nbytes"], _stream()), "conv_wgrad_partial")
         if not ent["used"]:
             ent["used"] = True
             self.order.append(key)

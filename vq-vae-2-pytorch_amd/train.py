@@ -61,6 +61,8 @@ class Stage1Trainer:
     def _late_grad_ready(self, _param):
         self._late_seen += 1
         if self._late_seen == 2 and not self._bucket_sent:
+            if self.wgrad_stream is not None:
+                torch.cuda.current_stream().wait_stream(self.wgrad_stream)
             self.wgrad_batch.flush()                      # reduce the split-K slabs produced so far
             ev = torch.cuda.current_stream().record_event()
             with torch.cuda.stream(self.comm_stream):
@@ -91,6 +93,8 @@ class Stage1Trainer:
         finally:
             ops.WGRAD_STREAM[0] = None
             ops.WGRAD_BATCH[0] = None
+        if self.wgrad_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)   # all slabs written
         self.wgrad_batch.flush()   # one launch reduces the split-K slabs of every layer into the arena
         if self.wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)   # all weight gradients have landed
