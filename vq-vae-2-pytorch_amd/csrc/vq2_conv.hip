@@ -46,7 +46,7 @@ struct ConvGemmParams {
 
 // BK = depth of one staged chunk; LDS rows are padded to BK+4 floats (144 B / 80 B), which makes the
 // ds_read_b128 fragment reads conflict-free (16-byte slot index = row*9 resp. row*5 mod 16).
-template <int WAVES_M, int WAVES_N, int MT, int NT, int BK, bool DEEP, bool STAMP = false>
+template <int WAVES_M, int WAVES_N, int MT, int NT, int BK, bool STAMP = false>
 __global__ __launch_bounds__(256, (MT * NT == 4) ? (BK == 16 ? 3 : 2) : 1) void conv_gemm_kernel(const ConvGemmParams P) {
     constexpr int LDK = BK + 4;
     constexpr int BM = WAVES_M * MT * 32;
@@ -112,9 +112,7 @@ __global__ __launch_bounds__(256, (MT * NT == 4) ? (BK == 16 ? 3 : 2) : 1) void 
         kw = tap - kh * P.KW;
     }
 
-    // Two register sets: chunk c+1 is written to LDS at the end of chunk c while chunk c+2 is already in
-    // flight (DEEP) -- global latency has two full MFMA phases (>= 8k cycles) to hide in.
-    float4 ra0[A_LD], rb0[B_LD], ra1[DEEP ? A_LD : 1], rb1[DEEP ? B_LD : 1];
+    float4 ra0[A_LD], rb0[B_LD];
     auto load_chunk = [&](float4 (&ra)[A_LD], float4 (&rb)[B_LD]) {
         const bool kv = kglob < P.K;
 #pragma unroll
@@ -195,7 +193,7 @@ __global__ __launch_bounds__(256, (MT * NT == 4) ? (BK == 16 ? 3 : 2) : 1) void 
     load_chunk(ra0, rb0);
     store_chunk(0, ra0, rb0);
     __syncthreads();
-    if constexpr (!DEEP) {
+    {
         unsigned long long t_load = 0, t_mfma = 0, t_store = 0, t_bar = 0;
         for (int c = 0; c < nchunks; ++c) {
             const int buf = c & 1;
@@ -221,20 +219,6 @@ __global__ __launch_bounds__(256, (MT * NT == 4) ? (BK == 16 ? 3 : 2) : 1) void 
                 P.stamps[wave * 4 + 0] = t_load; P.stamps[wave * 4 + 1] = t_mfma;
                 P.stamps[wave * 4 + 2] = t_store; P.stamps[wave * 4 + 3] = t_bar;
             }
-        }
-    } else {
-        // invariant at the top of an (even) iteration c: LDS[c&1] = chunk c, set0 = chunk c+1 (in flight)
-        if (nchunks > 1) { advance_k(); load_chunk(ra0, rb0); }
-        for (int c = 0; c < nchunks; c += 2) {
-            if (c + 2 < nchunks) { advance_k(); load_chunk(ra1, rb1); }       // chunk c+2
-            compute(0);
-            if (c + 1 < nchunks) store_chunk(1, ra0, rb0);                    // chunk c+1 -> LDS[1]
-            __syncthreads();
-            if (c + 1 >= nchunks) break;
-            if (c + 3 < nchunks) { advance_k(); load_chunk(ra0, rb0); }       // chunk c+3
-            compute(1);
-            if (c + 2 < nchunks) store_chunk(0, ra1, rb1);                    // chunk c+2 -> LDS[0]
-            __syncthreads();
         }
     }
 
@@ -561,12 +545,12 @@ static int launch_conv_gemm_fast(const ConvGemmParams &P, hipStream_t s) {
     return check_launch("conv_gemm_fast_kernel");
 }
 
-template <int WAVES_M, int WAVES_N, int MT, int NT, int BK, bool DEEP = false, bool STAMP = false>
+template <int WAVES_M, int WAVES_N, int MT, int NT, int BK, bool STAMP = false>
 static int launch_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
     constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
     static const int lds_pad = getenv("VQ2_LDS_PAD") ? atoi(getenv("VQ2_LDS_PAD")) : 0;  // experiments: force 1 WG/CU
     const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float) + lds_pad;
-    auto kern = conv_gemm_kernel<WAVES_M, WAVES_N, MT, NT, BK, DEEP, STAMP>;
+    auto kern = conv_gemm_kernel<WAVES_M, WAVES_N, MT, NT, BK, STAMP>;
     allow_big_lds(kern, lds);
     dim3 grid(((P.M + BM - 1) / BM) * ((P.Co + BN - 1) / BN) * P.phases);
     const char *name = "conv_gemm";
@@ -628,10 +612,8 @@ static int run_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
         return launch_conv_gemm<2, 2, 1, 1, 16>(P, s);                     // 64 x 64
     }
     if (P.Co > 64) {
-        static const int deep = tune("VQ2_DEEP", 0);
         if (bk128 == 16) return launch_conv_gemm<2, 2, 2, 2, 16>(P, s);
-        if (deep) return launch_conv_gemm<2, 2, 2, 2, 32, true>(P, s);     // 128 x 128, 2-deep register prefetch
-        if (g_stamps) { ConvGemmParams Q = P; Q.stamps = g_stamps; return launch_conv_gemm<2, 2, 2, 2, 32, false, true>(Q, s); }
+        if (g_stamps) { ConvGemmParams Q = P; Q.stamps = g_stamps; return launch_conv_gemm<2, 2, 2, 2, 32, true>(Q, s); }
         return launch_conv_gemm<2, 2, 2, 2, 32>(P, s);                     // 128 x 128
     }
     if (P.Co > 32) {
