@@ -291,6 +291,7 @@ __global__ __launch_bounds__(256, (MT * NT == 4) ? (BK == 16 ? 3 : 2) : 1) void 
 //   * per chunk: (tap, ci) advance without loops, tap offset from a small LDS table
 //   * epilogue: 32-bit offsets, one add per element; sub-pixel phases share one division per tile row
 // Limits (checked by the launcher): KH*KW <= 32, every tensor < 2 GiB.
+static int tune(const char *name, int dflt);
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int OOB = 0x7FFFFFF0;  // >= num_records of every descriptor: loads return 0, stores are dropped
 constexpr unsigned RSRC_FLAGS = 0x00020000;
@@ -299,7 +300,7 @@ __device__ __forceinline__ float4 as_f4(u32x4 v) {
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-template <int WAVES_M, int WAVES_N, int MT, int NT, int BK>
+template <int WAVES_M, int WAVES_N, int MT, int NT, int BK, bool PIPE>
 __global__ __launch_bounds__(256, (MT * NT == 4) ? 2 : 1) void conv_gemm_fast_kernel(const ConvGemmParams P) {
     constexpr int LDK = BK + 4;
     constexpr int BM = WAVES_M * MT * 32;
@@ -375,7 +376,11 @@ __global__ __launch_bounds__(256, (MT * NT == 4) ? 2 : 1) void conv_gemm_fast_ke
     __syncthreads();  // tap table visible
 
     u32x4 ra[A_LD], rb[B_LD];
-    auto load_chunk = [&]() {
+    // The byte offsets of a chunk's loads are computed one chunk AHEAD (prep_offsets, placed inside the
+    // previous chunk's MFMA phase), so that at the top of a chunk the wave only has to issue its 8 loads:
+    // no dependent LDS-table/VALU chain sits between the barrier and the first MFMA.
+    int off_a[A_LD], off_b[B_LD];
+    auto prep_offsets = [&]() {
         const bool kv = tap < ntaps;
         const int tsel = kv ? tap : 0;
         const int koff = tap_off[tsel] + ci * 4;
@@ -384,12 +389,18 @@ __global__ __launch_bounds__(256, (MT * NT == 4) ? 2 : 1) void conv_gemm_fast_ke
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
             const bool v = kv && (((a_hm[j] >> kh) & (a_wm[j] >> kw) & 1u) != 0u);
-            ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, v ? a_base[j] + koff : OOB, 0, 0);
+            off_a[j] = v ? a_base[j] + koff : OOB;
         }
 #pragma unroll
-        for (int j = 0; j < B_LD; ++j)
-            rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (kv && b_base[j] >= 0) ? b_base[j] + kglob * 4 : OOB, 0, 0);
+        for (int j = 0; j < B_LD; ++j) off_b[j] = (kv && b_base[j] >= 0) ? b_base[j] + kglob * 4 : OOB;
     };
+    auto issue_loads = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, off_a[j], 0, 0);
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, off_b[j], 0, 0);
+    };
+    auto load_chunk = [&]() { prep_offsets(); issue_loads(); };
     auto advance_k = [&]() {
         kglob += BK;
         ci += cstep;
@@ -419,7 +430,7 @@ __global__ __launch_bounds__(256, (MT * NT == 4) ? 2 : 1) void conv_gemm_fast_ke
 
     const int frag_row = lane & 31;
     const int frag_k = 4 * (lane >> 5);
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf, bool prep_next) {
         const float *a = As + buf * BM * LDK + (wm * MT * 32 + frag_row) * LDK + frag_k;
         const float *b = Bs + buf * BN * LDK + (wn * NT * 32 + frag_row) * LDK + frag_k;
         float4 fa[2][MT], fb[2][NT];
@@ -441,6 +452,7 @@ __global__ __launch_bounds__(256, (MT * NT == 4) ? 2 : 1) void conv_gemm_fast_ke
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].C, fb[cur][j].C, acc[i][j], 0, 0, 0);
             VQ2_MFMA_STEP(x) VQ2_MFMA_STEP(y) VQ2_MFMA_STEP(z) VQ2_MFMA_STEP(w)
 #undef VQ2_MFMA_STEP
+            if (PIPE && k8 == 0 && prep_next) { advance_k(); prep_offsets(); }   // offsets of chunk c+2, in the MFMA shadow
         }
     };
 
@@ -448,15 +460,26 @@ __global__ __launch_bounds__(256, (MT * NT == 4) ? 2 : 1) void conv_gemm_fast_ke
     load_chunk();
     store_chunk(0);
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunks) {
-            advance_k();
-            load_chunk();
+    if constexpr (PIPE) {
+        if (nchunks > 1) { advance_k(); prep_offsets(); }      // offsets of chunk 1
+        for (int c = 0; c < nchunks; ++c) {
+            const int buf = c & 1;
+            if (c + 1 < nchunks) issue_loads();                // chunk c+1 (offsets ready since last iteration)
+            compute(buf, c + 2 < nchunks);
+            if (c + 1 < nchunks) store_chunk(buf ^ 1);
+            __syncthreads();
         }
-        compute(buf);
-        if (c + 1 < nchunks) store_chunk(buf ^ 1);
-        __syncthreads();
+    } else {
+        for (int c = 0; c < nchunks; ++c) {
+            const int buf = c & 1;
+            if (c + 1 < nchunks) {
+                advance_k();
+                load_chunk();
+            }
+            compute(buf, false);
+            if (c + 1 < nchunks) store_chunk(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue with 32-bit offsets through buffer descriptors
@@ -533,7 +556,9 @@ template <int WAVES_M, int WAVES_N, int MT, int NT, int BK>
 static int launch_conv_gemm_fast(const ConvGemmParams &P, hipStream_t s) {
     constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
     const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float) + 64 * sizeof(int);
-    auto kern = conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK>;
+    static const int pipe = tune("VQ2_PIPE", 1);
+    auto kern = pipe ? conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, true>
+                     : conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, false>;
     allow_big_lds(kern, lds);
     dim3 grid(((P.M + BM - 1) / BM) * ((P.Co + BN - 1) / BN) * P.phases);
     const char *name = "conv_gemm";
