@@ -126,6 +126,7 @@ typedef struct vq2_wgrad_job {
     float *db;            /* bias gradient destination or NULL                  */
     int64_t unit_offset;  /* start of this job in the batched unit space        */
     int32_t O, I, Or, Ir, taps, S, n_units_w, n_units_b;
+    int32_t swapped, reserved; /* slab is [ci][flipped tap][co] (roles of x and dy exchanged) */
 } vq2_wgrad_job;
 int vq2_conv_wgrad_partial(const vq2_conv_desc *d, int flags, const float *x, const float *dy, float *db, void *ws,
                            size_t ws_bytes, vq2_stream_t stream);

@@ -374,7 +374,8 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
 // S/32 times instead of S times.  The last workgroup also folds the bias partials.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, int O,
                                                            int I, int Or, int Ir, int taps, int S,
-                                                           const float *__restrict__ bias_ws, float *__restrict__ db) {
+                                                           const float *__restrict__ bias_ws, float *__restrict__ db,
+                                                           int swapped) {
     __shared__ float part[8][33];
     const int K = taps * I;
     const int total = O * K;
@@ -400,7 +401,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
             for (int q = 1; q < 8; ++q) s += part[q][lane];
             const int o = t / K, k = t - o * K;
             const int tap = k / I, i = k - tap * I;
-            if (o < Or && i < Ir) dw[((size_t)o * Ir + i) * taps + tap] = s;
+            if (o < Or && i < Ir) {
+                if (swapped) dw[((size_t)i * Or + o) * taps + (taps - 1 - tap)] = s;   // slab is [ci][flipped tap][co]
+                else dw[((size_t)o * Ir + i) * taps + tap] = s;
+            }
         }
         __syncthreads();
     }
@@ -468,7 +472,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const vq2_wgr
             } else {
                 const int o = t / K, k = t - o * K;
                 const int tap = k / j.I, i = k - tap * j.I;
-                if (o < j.Or && i < j.Ir) j.dw[((size_t)o * j.Ir + i) * j.taps + tap] = s;
+                if (o < j.Or && i < j.Ir) {
+                    if (j.swapped) j.dw[((size_t)i * j.Or + o) * j.taps + (j.taps - 1 - tap)] = s;
+                    else j.dw[((size_t)o * j.Ir + i) * j.taps + tap] = s;
+                }
             }
         }
         __syncthreads();
@@ -477,11 +484,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const vq2_wgr
 
 struct WgradPlan {
     int O, I, K, M, S, rows_per_split, bmo, bnk;
+    int swapped;  // roles of x and dy exchanged (see plan_wgrad)
 };
 
 static WgradPlan plan_wgrad(const vq2_conv_desc *d) {
     WgradPlan p;
-    if (!d->transposed) {
+    p.swapped = 0;
+    // A stride-1 "same" conv with few output channels (the ResBlock 3x3, 128 -> 32): gathering the im2col
+    // of the WIDE tensor x re-reads it KH*KW times through L2.  The same sum with the roles exchanged,
+    //   dw[co][ci][kh][kw] = sum_q relu(x)[q][ci] * dy[q - (kh-p, kw-p)][co],
+    // gathers the NARROW tensor dy instead (flipped taps, pad' = K-1-p) and streams x once.
+    static const int wswap = getenv("VQ2_WSWAP") ? atoi(getenv("VQ2_WSWAP")) : 1;
+    if (wswap && !d->transposed && d->stride == 1 && 2 * d->pad == d->KH - 1 && d->KH > 1 && d->Co <= 32 && d->Ci >= 64) {
+        p.swapped = 1;
+        p.O = d->Ci; p.I = d->Co;
+        p.M = d->N * d->H * d->W;
+    } else if (!d->transposed) {
         p.O = d->Co; p.I = d->Ci;
         const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
         p.M = d->N * Ho * Wo;
@@ -630,11 +648,17 @@ static int wgrad_impl(const vq2_conv_desc *d, int flags, const float *x, const f
     P.ws = static_cast<float *>(ws);
     float *bias_ws = P.ws + (size_t)p.S * p.O * p.K;       // [S][O] bias partials (conv only)
     float *colsum_ws = bias_ws + (size_t)p.S * p.O;        // convT: separate column-sum pass over dy
-    P.bias_ws = (db && !d->transposed) ? bias_ws : nullptr;
+    P.bias_ws = (db && !d->transposed && !p.swapped) ? bias_ws : nullptr;
     P.KH = d->KH; P.KW = d->KW; P.stride = d->stride; P.pad = d->pad;
     P.O = p.O; P.I = p.I; P.K = p.K; P.M = p.M; P.rows_per_split = p.rows_per_split;
     P.N = d->N;
-    if (!d->transposed) {
+    if (p.swapped) {
+        P.x = dy; P.ldx = d->ldy; P.H = d->H; P.W = d->W;       // gathered operand: dy (same spatial size as x)
+        P.g = x; P.ldg = d->ldx;
+        P.Ho = d->H; P.Wo = d->W;
+        P.stride = 1; P.pad = d->KH - 1 - d->pad;
+        P.relu_x = 0; P.relu_g = (flags & VQ2_RELU_IN) != 0;
+    } else if (!d->transposed) {
         P.x = x; P.ldx = d->ldx; P.H = d->H; P.W = d->W;
         P.g = dy; P.ldg = d->ldy;
         P.Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1; P.Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
@@ -654,7 +678,7 @@ static int wgrad_impl(const vq2_conv_desc *d, int flags, const float *x, const f
     const double pix_out_ = d->transposed ? 4.0 * pix_in_ : (double)P.M;
     const double macs_ = d->transposed ? pix_in_ * 16.0 * cir_ * cor_ : pix_out_ * d->KH * d->KW * cir_ * cor_;
     const char *pname = "wgrad";
-    if (prof_enabled()) pname = prof_label("wgrad<%dx%d>|O=%d,K=%d,M=%d,S=%d,k%d", p.bmo, p.bnk, p.O, p.K, p.M, p.S, d->KH);
+    if (prof_enabled()) pname = prof_label("wgrad<%dx%d>%s|O=%d,K=%d,M=%d,S=%d,k%d", p.bmo, p.bnk, p.swapped ? "sw" : "", p.O, p.K, p.M, p.S, d->KH);
     ProfScope prof(pname, 2.0 * macs_, 4.0 * (pix_in_ * cir_ + pix_out_ * cor_ + cir_ * cor_ * d->KH * d->KW), s);
     if (p.bmo == 128 && p.bnk == 128) e = launch_wgrad<2, 2, 2, 2>(P, p.S, s);
     else if (p.bmo == 64 && p.bnk == 128) e = launch_wgrad<1, 4, 2, 1>(P, p.S, s);
@@ -663,19 +687,20 @@ static int wgrad_impl(const vq2_conv_desc *d, int flags, const float *x, const f
     else e = launch_wgrad<2, 2, 1, 1>(P, p.S, s);                       // 64 x 64
     if (e) return e;
     if (!reduce) {
-        if (db && d->transposed) {
-            const int cor2 = d->Cor ? d->Cor : d->Co;
-            return colsum_impl(dy, (int64_t)d->N * 4 * d->H * d->W, d->Co, d->ldy, db, cor2, colsum_ws, s);
-        }
+        const int cor2 = d->Cor ? d->Cor : d->Co;
+        if (db && d->transposed) return colsum_impl(dy, (int64_t)d->N * 4 * d->H * d->W, d->Co, d->ldy, db, cor2, colsum_ws, s);
+        if (db && p.swapped) return colsum_impl(dy, (int64_t)p.M, d->Co, d->ldy, db, cor2, colsum_ws, s);
         return VQ2_OK;
     }
     const int total = p.O * p.K;
     const int blocks = (total + 31) / 32 < 4096 ? (total + 31) / 32 : 4096;
     const int cir = d->Cir ? d->Cir : d->Ci, cor = d->Cor ? d->Cor : d->Co;
-    const int Or = d->transposed ? cir : cor, Ir = d->transposed ? cor : cir;
+    const bool sw = d->transposed || p.swapped;
+    const int Or = sw ? cir : cor, Ir = sw ? cor : cir;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, P.ws, dw, p.O, p.I, Or, Ir, d->KH * d->KW,
-                       p.S, P.bias_ws, db);
+                       p.S, P.bias_ws, db, p.swapped);
     if (int e2 = check_launch("wgrad_reduce_kernel")) return e2;
+    if (db && p.swapped) return colsum_impl(dy, (int64_t)p.M, d->Co, d->ldy, db, cor, colsum_ws, s);
     if (db && d->transposed) {  // bias gradient of a conv-transpose = column sums of dy [N,2H,2W,Co]
         const int64_t rows = (int64_t)d->N * 4 * d->H * d->W;
         return colsum_impl(dy, rows, d->Co, d->ldy, db, cor, colsum_ws, s);
@@ -699,11 +724,13 @@ extern "C" int vq2_wgrad_job_init(const vq2_conv_desc *d, const void *ws, float 
     const int cir = d->Cir ? d->Cir : d->Ci, cor = d->Cor ? d->Cor : d->Co;
     const float *w = static_cast<const float *>(ws);
     job->ws = w; job->dw = dw; job->db = nullptr; job->bias_ws = nullptr;
-    job->O = p.O; job->I = p.I; job->Or = d->transposed ? cir : cor; job->Ir = d->transposed ? cor : cir;
+    const bool sw = d->transposed || p.swapped;
+    job->O = p.O; job->I = p.I; job->Or = sw ? cir : cor; job->Ir = sw ? cor : cir;
+    job->swapped = p.swapped; job->reserved = 0;
     job->taps = d->KH * d->KW; job->S = p.S;
     job->n_units_w = (p.O * p.K + 31) / 32;
     job->n_units_b = 0;
-    if (db && !d->transposed) {   // conv-transpose bias gradients are produced by the partial call itself
+    if (db && !d->transposed && !p.swapped) {   // the other cases produce db in the partial call itself
         job->db = db; job->bias_ws = w + (size_t)p.S * p.O * p.K;
         job->n_units_b = (job->Or + 31) / 32;
     }
