@@ -300,8 +300,8 @@ __device__ __forceinline__ float4 as_f4(u32x4 v) {
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-template <int WAVES_M, int WAVES_N, int MT, int NT, int BK, bool PIPE>
-__global__ __launch_bounds__(256, (MT * NT == 4) ? 2 : 1) void conv_gemm_fast_kernel(const ConvGemmParams P) {
+template <int WAVES_M, int WAVES_N, int MT, int NT, int BK, bool PIPE, bool RELU_IN>
+__global__ __launch_bounds__(256, (MT * NT == 4) ? (BK == 16 ? 3 : 2) : 1) void conv_gemm_fast_kernel(const ConvGemmParams P) {
     constexpr int LDK = BK + 4;
     constexpr int BM = WAVES_M * MT * 32;
     constexpr int BN = WAVES_N * NT * 32;
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256, (MT * NT == 4) ? 2 : 1) void conv_gemm_fast_ke
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
             const float4 v = as_f4(ra[j]);
-            *reinterpret_cast<float4 *>(a + (lrow + RPP * j) * LDK + lk) = P.relu_in ? relu4(v) : v;
+            *reinterpret_cast<float4 *>(a + (lrow + RPP * j) * LDK + lk) = RELU_IN ? relu4(v) : v;   // compile-time: no select
         }
 #pragma unroll
         for (int j = 0; j < B_LD; ++j)
@@ -557,8 +557,10 @@ static int launch_conv_gemm_fast(const ConvGemmParams &P, hipStream_t s) {
     constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
     const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float) + 64 * sizeof(int);
     static const int pipe = tune("VQ2_PIPE", 1);
-    auto kern = pipe ? conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, true>
-                     : conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, false>;
+    auto kern = P.relu_in ? (pipe ? conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, true, true>
+                                  : conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, false, true>)
+                          : (pipe ? conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, true, false>
+                                  : conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, false, false>);
     allow_big_lds(kern, lds);
     dim3 grid(((P.M + BM - 1) / BM) * ((P.Co + BN - 1) / BN) * P.phases);
     const char *name = "conv_gemm";
@@ -621,6 +623,8 @@ static int run_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
         if (P.Co > 64) {
             if (tk == 1 && P.K <= 512) return launch_conv_gemm_fast<2, 2, 1, 2, 16>(P, s);   // 64 x 128 for short K
             if (tk == 2 && P.K <= 512) return launch_conv_gemm_fast<2, 2, 1, 2, 32>(P, s);
+            static const int t128 = tune("VQ2_T128", 0);
+            if (t128 == 1) return launch_conv_gemm_fast<2, 2, 2, 2, 16>(P, s);   // 3 workgroups per CU
             return launch_conv_gemm_fast<2, 2, 2, 2, 32>(P, s);
         }
         if (P.Co > 32) {

@@ -203,7 +203,7 @@ __device__ __forceinline__ float4 as_f4w(u32x4w v) {
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-template <int WAVES_M, int WAVES_N, int MT, int NT>
+template <int WAVES_M, int WAVES_N, int MT, int NT, bool RELU_X, bool RELU_G>
 __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
     constexpr int BMO = WAVES_M * MT * 32;
     constexpr int BNK = WAVES_N * NT * 32;
@@ -294,12 +294,12 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
 #pragma unroll
         for (int j = 0; j < G_LD; ++j) {
             const float4 v = as_f4w(rgv[j]);
-            *reinterpret_cast<float4 *>(gs + (g_r + j * G_RSTEP) * BMO + (tid % G_C4) * 4) = P.relu_g ? relu4(v) : v;
+            *reinterpret_cast<float4 *>(gs + (g_r + j * G_RSTEP) * BMO + (tid % G_C4) * 4) = RELU_G ? relu4(v) : v;
         }
 #pragma unroll
         for (int j = 0; j < X_LD; ++j) {
             const float4 v = as_f4w(rxv[j]);
-            *reinterpret_cast<float4 *>(xs + (x_r + j * X_RSTEP) * BNK + (tid % X_C4) * 4) = P.relu_x ? relu4(v) : v;
+            *reinterpret_cast<float4 *>(xs + (x_r + j * X_RSTEP) * BNK + (tid % X_C4) * 4) = RELU_X ? relu4(v) : v;
         }
     };
 
@@ -540,7 +540,12 @@ static int launch_wgrad(const WgradParams &P, int S, hipStream_t s) {
     const long lim = 1L << 29;
     const bool fast_ok = fast && P.Wo % WG_BKR == 0 && P.rows_per_split % WG_BKR == 0 &&
                          (long)P.N * P.H * P.W * P.ldx < lim && (long)P.M * P.ldg < lim;
-    auto kern = fast_ok ? wgrad_fast_kernel<WAVES_M, WAVES_N, MT, NT> : wgrad_kernel<WAVES_M, WAVES_N, MT, NT>;
+    auto kern = wgrad_kernel<WAVES_M, WAVES_N, MT, NT>;
+    if (fast_ok) {   // ReLU flags are compile-time in the fast kernel: every vector instruction competes with the MFMAs
+        if (P.relu_x) kern = wgrad_fast_kernel<WAVES_M, WAVES_N, MT, NT, true, false>;
+        else if (P.relu_g) kern = wgrad_fast_kernel<WAVES_M, WAVES_N, MT, NT, false, true>;
+        else kern = wgrad_fast_kernel<WAVES_M, WAVES_N, MT, NT, false, false>;
+    }
     allow_big_lds(kern, lds);
     dim3 grid(((P.K + BNK - 1) / BNK) * ((P.O + BMO - 1) / BMO) * S);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, P);
