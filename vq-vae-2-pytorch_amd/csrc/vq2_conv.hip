@@ -347,11 +347,11 @@ __global__ __launch_bounds__(256, (MT * NT == 4) ? (BK == 16 ? 3 : 2) : 1) void 
     const int lk = (tid % KQ) * 4;
     const int HoWo = P.Ho * P.Wo;
     int a_base[A_LD];
-    unsigned a_hm[A_LD], a_wm[A_LD];
+    unsigned a_vw[A_LD];   // bit t: tap t = (kh, kw) of this row lies inside the image
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
         const int m = m0 + lrow + RPP * j;
-        a_base[j] = 0; a_hm[j] = 0; a_wm[j] = 0;
+        a_base[j] = 0; a_vw[j] = 0;
         if (m < P.M) {
             const int n = m / HoWo;
             const int r = m - n * HoWo;
@@ -359,8 +359,11 @@ __global__ __launch_bounds__(256, (MT * NT == 4) ? (BK == 16 ? 3 : 2) : 1) void 
             const int wo = r - ho * P.Wo;
             const int hb = ho * P.stride - pad_h, wb = wo * P.stride - pad_w;
             a_base[j] = ((n * P.H + hb) * P.W + wb) * P.ldx * 4;
-            for (int q = 0; q < P.KH; ++q) a_hm[j] |= ((unsigned)(hb + q) < (unsigned)P.H ? 1u : 0u) << q;
-            for (int q = 0; q < P.KW; ++q) a_wm[j] |= ((unsigned)(wb + q) < (unsigned)P.W ? 1u : 0u) << q;
+            unsigned hm = 0, wmk = 0;
+            for (int q = 0; q < P.KH; ++q) hm |= ((unsigned)(hb + q) < (unsigned)P.H ? 1u : 0u) << q;
+            for (int q = 0; q < P.KW; ++q) wmk |= ((unsigned)(wb + q) < (unsigned)P.W ? 1u : 0u) << q;
+            for (int q = 0; q < P.KH; ++q)
+                if ((hm >> q) & 1u) a_vw[j] |= wmk << (q * P.KW);
         }
     }
     int b_base[B_LD];
@@ -380,15 +383,15 @@ __global__ __launch_bounds__(256, (MT * NT == 4) ? (BK == 16 ? 3 : 2) : 1) void 
     // previous chunk's MFMA phase), so that at the top of a chunk the wave only has to issue its 8 loads:
     // no dependent LDS-table/VALU chain sits between the barrier and the first MFMA.
     int off_a[A_LD], off_b[B_LD];
+    // K % BK == 0 (every layer of this model): a chunk never runs past K, no tail predicate needed
+    const bool k_aligned = (P.K % BK) == 0;
     auto prep_offsets = [&]() {
-        const bool kv = tap < ntaps;
+        const bool kv = k_aligned || tap < ntaps;
         const int tsel = kv ? tap : 0;
         const int koff = tap_off[tsel] + ci * 4;
-        const int khw = tap_khw[tsel];
-        const int kh = khw & 255, kw = khw >> 8;
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
-            const bool v = kv && (((a_hm[j] >> kh) & (a_wm[j] >> kw) & 1u) != 0u);
+            const bool v = kv && ((a_vw[j] >> tsel) & 1u) != 0u;
             off_a[j] = v ? a_base[j] + koff : OOB;
         }
 #pragma unroll
