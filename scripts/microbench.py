@@ -57,9 +57,12 @@ def main():
         dy = torch.randn(n, ho, wo, spec.co, device=dev)
         macs = (n * h * w * 16 if spec.transposed else n * ho * wo * spec.k * spec.k) * spec.cin * spec.cout
         fl = 2.0 * macs
-        t_f = timeit(lambda: ops.conv_forward(spec, x, wt, b, ops.VQ2_RELU_IN))
+        relu = 0 if os.environ.get("MB_NORELU") else ops.VQ2_RELU_IN
+        t_f = timeit(lambda: ops.conv_forward(spec, x, wt, b, relu))
         t_d = timeit(lambda: ops.conv_dgrad(spec, x.shape, dy, wt, mask=x))
         t_w = timeit(lambda: ops.conv_wgrad(spec, x, dy, True, wt, b))
+        if os.environ.get("MB_REPEAT"):
+            t_f = timeit(lambda: ops.conv_forward(spec, x, wt, b, relu))   # again, after the clocks have settled
         print(f"{name:14s} fwd {t_f:8.1f} us {fl / t_f / 1e6:6.1f} TF | dgrad {t_d:8.1f} us {fl / t_d / 1e6:6.1f} TF | "
               f"wgrad {t_w:8.1f} us {fl / t_w / 1e6:6.1f} TF", flush=True)
 
