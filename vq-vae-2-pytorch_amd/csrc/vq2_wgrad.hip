@@ -151,18 +151,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
         }
         const float *gs = Gs + buf * WG_BKR * BMO + fk * BMO + wm * MT * 32 + fr;
         const float *xs = Xs + buf * WG_BKR * BNK + fk * BNK + wn * NT * 32 + fr;
+        // fragments double-buffered: the ds_reads of k-step kk+1 are in flight during the MFMAs of step kk
+        float fa[2][MT], fb[2][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[0][i] = gs[i * 32];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[0][j] = xs[j * 32];
 #pragma unroll
         for (int kk = 0; kk < WG_BKR / 2; ++kk) {
-            float fa[MT], fb[NT];
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < WG_BKR / 2) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) fa[i] = gs[kk * 2 * BMO + i * 32];
+                for (int i = 0; i < MT; ++i) fa[nxt][i] = gs[(kk + 1) * 2 * BMO + i * 32];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) fb[j] = xs[kk * 2 * BNK + j * 32];
+                for (int j = 0; j < NT; ++j) fb[nxt][j] = xs[(kk + 1) * 2 * BNK + j * 32];
+            }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+            // pin the order: next step's LDS reads first, then this step's MFMAs (hipcc otherwise sinks the
+            // reads to just before their use and waits lgkmcnt(0) in front of every MFMA group)
+            __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
         }
         if (c + 1 < nchunks) store_chunk(buf ^ 1);
         __syncthreads();
@@ -332,18 +344,30 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
         }
         const float *gs = Gs + buf * WG_BKR * BMO + fk * BMO + wm * MT * 32 + fr;
         const float *xs = Xs + buf * WG_BKR * BNK + fk * BNK + wn * NT * 32 + fr;
+        // fragments double-buffered: the ds_reads of k-step kk+1 are in flight during the MFMAs of step kk
+        float fa[2][MT], fb[2][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[0][i] = gs[i * 32];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[0][j] = xs[j * 32];
 #pragma unroll
         for (int kk = 0; kk < WG_BKR / 2; ++kk) {
-            float fa[MT], fb[NT];
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < WG_BKR / 2) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) fa[i] = gs[kk * 2 * BMO + i * 32];
+                for (int i = 0; i < MT; ++i) fa[nxt][i] = gs[(kk + 1) * 2 * BMO + i * 32];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) fb[j] = xs[kk * 2 * BNK + j * 32];
+                for (int j = 0; j < NT; ++j) fb[nxt][j] = xs[(kk + 1) * 2 * BNK + j * 32];
+            }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+            // pin the order: next step's LDS reads first, then this step's MFMAs (hipcc otherwise sinks the
+            // reads to just before their use and waits lgkmcnt(0) in front of every MFMA group)
+            __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
         }
         if (c + 1 < nchunks) store_chunk(buf ^ 1);
         __syncthreads();
