@@ -22,6 +22,7 @@ struct WgradParams {
     const float *g;  // grad  operand [N,Ho,Wo,ldg], O channels
     float *ws;       // [S][O][K] partial slabs
     float *bias_ws;  // [S][O] partial column sums of g (bias gradient) or null
+    int bias_from_x; // exchanged roles: bias = column sums of the CENTRE-tap block of the gathered operand; k offset of that block + 1 (0 = off)
     int N, H, W, I, ldx;
     int Ho, Wo, O, ldg;
     int KH, KW, stride, pad;
@@ -137,7 +138,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
     }
     __syncthreads();
     const int fr = lane & 31, fk = lane >> 5;
-    const bool do_bias = P.bias_ws != nullptr && k0 == 0 && tid < BMO;
+    const bool do_bias = P.bias_ws != nullptr && !P.bias_from_x && k0 == 0 && tid < BMO;
+    const bool do_bias_x = P.bias_ws != nullptr && P.bias_from_x && k0 == P.bias_from_x - 1 && o0 == 0 && tid < BNK;
     float bsum = 0.f;
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
@@ -147,6 +149,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
             for (int r = 0; r < WG_BKR; r += 2) { s0 += gcol[r * BMO]; s1 += gcol[(r + 1) * BMO]; }
+            bsum += s0 + s1;
+        }
+        if (do_bias_x) {
+            const float *xcol = Xs + buf * WG_BKR * BNK + tid;
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < WG_BKR; r += 2) { s0 += xcol[r * BNK]; s1 += xcol[(r + 1) * BNK]; }
             bsum += s0 + s1;
         }
         const float *gs = Gs + buf * WG_BKR * BMO + fk * BMO + wm * MT * 32 + fr;
@@ -181,6 +190,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
     }
 
     if (do_bias && o0 + tid < P.O) P.bias_ws[(size_t)split * P.O + o0 + tid] = bsum;
+    if (do_bias_x && tid < P.I) P.bias_ws[(size_t)split * P.I + tid] = bsum;
 
     // partial tile -> slab [split][o][k]
     float *slab = P.ws + (size_t)split * P.O * P.K;
@@ -330,7 +340,10 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
     }
     __syncthreads();
     const int fr = lane & 31, fk = lane >> 5;
-    const bool do_bias = P.bias_ws != nullptr && k0 == 0 && tid < BMO;
+    const bool do_bias = P.bias_ws != nullptr && !P.bias_from_x && k0 == 0 && tid < BMO;
+    // exchanged roles: dy is the gathered operand; its centre tap visits every pixel exactly once, so the
+    // column sums of that k-block of the staged X tile are the bias gradient (tile width == one tap)
+    const bool do_bias_x = P.bias_ws != nullptr && P.bias_from_x && k0 == P.bias_from_x - 1 && o0 == 0 && tid < BNK;
     float bsum = 0.f;
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
@@ -340,6 +353,13 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
             for (int r = 0; r < WG_BKR; r += 2) { s0 += gcol[r * BMO]; s1 += gcol[(r + 1) * BMO]; }
+            bsum += s0 + s1;
+        }
+        if (do_bias_x) {
+            const float *xcol = Xs + buf * WG_BKR * BNK + tid;
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < WG_BKR; r += 2) { s0 += xcol[r * BNK]; s1 += xcol[(r + 1) * BNK]; }
             bsum += s0 + s1;
         }
         const float *gs = Gs + buf * WG_BKR * BMO + fk * BMO + wm * MT * 32 + fr;
@@ -373,6 +393,7 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
         __syncthreads();
     }
     if (do_bias && o0 + tid < P.O) P.bias_ws[(size_t)split * P.O + o0 + tid] = bsum;
+    if (do_bias_x && tid < P.I) P.bias_ws[(size_t)split * P.I + tid] = bsum;
 
     float *slab = P.ws + (size_t)split * P.O * P.K;
     const int colq = lane & 31, rowq = 4 * (lane >> 5);
@@ -433,14 +454,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
         __syncthreads();
     }
     if (db && bias_ws && blockIdx.x == gridDim.x - 1) {
-        for (int base = 0; base < Or; base += 32) {
+        const int bstride = swapped ? I : O, blimit = swapped ? Ir : Or;
+        for (int base = 0; base < blimit; base += 32) {
             const int o = base + lane;
             float s0 = 0.f;
-            if (o < Or)
-                for (int z = g; z < S; z += 8) s0 += bias_ws[(size_t)z * O + o];
+            if (o < blimit)
+                for (int z = g; z < S; z += 8) s0 += bias_ws[(size_t)z * bstride + o];
             part[g][lane] = s0;
             __syncthreads();
-            if (g == 0 && o < Or) {
+            if (g == 0 && o < blimit) {
                 float s = part[0][lane];
 #pragma unroll
                 for (int q = 1; q < 8; ++q) s += part[q][lane];
@@ -470,8 +492,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const vq2_wgr
         const int lu = (int)(u - j.unit_offset);
         const bool is_bias = lu >= j.n_units_w;
         const int K = j.taps * j.I;
-        const int total = is_bias ? j.O : j.O * K;      // stride between splits
-        const int limit = is_bias ? j.Or : j.O * K;
+        const int total = is_bias ? (j.swapped ? j.I : j.O) : j.O * K;      // stride between splits
+        const int limit = is_bias ? (j.swapped ? j.Ir : j.Or) : j.O * K;
         const float *src = is_bias ? j.bias_ws : j.ws;
         const int t = (is_bias ? lu - j.n_units_w : lu) * 32 + lane;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -678,6 +700,12 @@ static int wgrad_impl(const vq2_conv_desc *d, int flags, const float *x, const f
     float *bias_ws = P.ws + (size_t)p.S * p.O * p.K;       // [S][O] bias partials (conv only)
     float *colsum_ws = bias_ws + (size_t)p.S * p.O;        // convT: separate column-sum pass over dy
     P.bias_ws = (db && !d->transposed && !p.swapped) ? bias_ws : nullptr;
+    P.bias_from_x = 0;
+    const bool bias_x = db && p.swapped && p.bnk == p.I;   // one tap per k-tile
+    if (bias_x) {
+        P.bias_ws = bias_ws;
+        P.bias_from_x = ((d->KH / 2) * d->KW + d->KW / 2) * p.I + 1;   // the centre tap is its own flip
+    }
     P.KH = d->KH; P.KW = d->KW; P.stride = d->stride; P.pad = d->pad;
     P.O = p.O; P.I = p.I; P.K = p.K; P.M = p.M; P.rows_per_split = p.rows_per_split;
     P.N = d->N;
@@ -718,7 +746,7 @@ static int wgrad_impl(const vq2_conv_desc *d, int flags, const float *x, const f
     if (!reduce) {
         const int cor2 = d->Cor ? d->Cor : d->Co;
         if (db && d->transposed) return colsum_impl(dy, (int64_t)d->N * 4 * d->H * d->W, d->Co, d->ldy, db, cor2, colsum_ws, s);
-        if (db && p.swapped) return colsum_impl(dy, (int64_t)p.M, d->Co, d->ldy, db, cor2, colsum_ws, s);
+        if (db && p.swapped && !bias_x) return colsum_impl(dy, (int64_t)p.M, d->Co, d->ldy, db, cor2, colsum_ws, s);
         return VQ2_OK;
     }
     const int total = p.O * p.K;
@@ -729,7 +757,7 @@ static int wgrad_impl(const vq2_conv_desc *d, int flags, const float *x, const f
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, P.ws, dw, p.O, p.I, Or, Ir, d->KH * d->KW,
                        p.S, P.bias_ws, db, p.swapped);
     if (int e2 = check_launch("wgrad_reduce_kernel")) return e2;
-    if (db && p.swapped) return colsum_impl(dy, (int64_t)p.M, d->Co, d->ldy, db, cor, colsum_ws, s);
+    if (db && p.swapped && !bias_x) return colsum_impl(dy, (int64_t)p.M, d->Co, d->ldy, db, cor, colsum_ws, s);
     if (db && d->transposed) {  // bias gradient of a conv-transpose = column sums of dy [N,2H,2W,Co]
         const int64_t rows = (int64_t)d->N * 4 * d->H * d->W;
         return colsum_impl(dy, rows, d->Co, d->ldy, db, cor, colsum_ws, s);
@@ -759,9 +787,10 @@ extern "C" int vq2_wgrad_job_init(const vq2_conv_desc *d, const void *ws, float 
     job->taps = d->KH * d->KW; job->S = p.S;
     job->n_units_w = (p.O * p.K + 31) / 32;
     job->n_units_b = 0;
-    if (db && !d->transposed && !p.swapped) {   // the other cases produce db in the partial call itself
+    const bool bias_x = db && p.swapped && p.bnk == p.I;
+    if (db && !d->transposed && (!p.swapped || bias_x)) {   // the other cases produce db in the partial call itself
         job->db = db; job->bias_ws = w + (size_t)p.S * p.O * p.K;
-        job->n_units_b = (job->Or + 31) / 32;
+        job->n_units_b = ((p.swapped ? job->Ir : job->Or) + 31) / 32;
     }
     job->unit_offset = 0;
     return VQ2_OK;
