@@ -100,6 +100,18 @@ int vq2_pack_weights_batched(const vq2_pack_job *jobs_dev, int32_t njobs, int64_
 int vq2_conv_fwd(const vq2_conv_desc *d, int flags, const float *x, const float *wp, const float *bias,
                  const float *residual, int32_t ldres, float *y, vq2_stream_t stream);
 
+/* Fused ResBlock forward (vqvae.py:81-96), one launch:
+ *     r = relu(conv3x3(relu(x)) + b1)        [N,H,W,Cm]  pixel stride ldr  (saved for the backward pass)
+ *     y = [relu]( conv1x1(r) + b2 + x )      [N,H,W,C]   pixel stride ldy
+ * w1p / w2p: VQ2_PACK_FWD panels of the 3x3 (Cm x C) and 1x1 (C x Cm) weights.  flags: VQ2_RELU_OUT only
+ * (the trailing ReLU of Encoder/Decoder, vqvae.py:122,144).  Built for C = 128, Cm = 32 (the reference's
+ * channel / n_res_channel defaults): vq2_resblock_supported() says whether a (C, Cm) pair can take this
+ * path; otherwise the caller composes the block from two vq2_conv_fwd launches. */
+int vq2_resblock_supported(int32_t C, int32_t Cm);
+int vq2_resblock_fwd(int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cm, int flags, const float *x, int32_t ldx,
+                     const float *w1p, const float *b1, const float *w2p, const float *b2, float *r, int32_t ldr,
+                     float *y, int32_t ldy, vq2_stream_t stream);
+
 /* dx = dgrad(dy) [* (mask > 0)] [+ residual]
  * wp: VQ2_PACK_DGRAD packing of w.  mask (shape of x, pixel stride ldmask): the
  * pre-ReLU input when the forward op had VQ2_RELU_IN (ReLU backward fused);

@@ -180,3 +180,49 @@ def test_checkpoint_round_trip_reference_format(amd):
     # the same checkpoint drives the CPU oracle (i.e. the reference layout) to the same output
     ref, _, _, _ = O.vqvae_forward({k: v.clone() for k, v in sd.items()}, cfg, img.cpu(), training=False)
     close(a, ref)
+
+
+@pytest.mark.parametrize("shape", [(1, 13, 21), (2, 8, 16), (3, 5, 40), (5, 64, 64)])
+def test_fused_resblock_forward_backward(amd, shape):
+    """One-launch ResBlock (csrc/vq2_resblock.hip; 128/32 channels) vs the oracle's vqvae.py:85-94:
+    ragged tiles, channel-slice input/output, trailing ReLU."""
+    from vqvae2_amd import ops
+    dev = torch.device("cuda:0")
+    n, h, w = shape
+    blk = amd.ResBlock(128, 32).to(dev)
+    assert ops.lib.vq2_resblock_supported(128, 32) == 1 and ops.lib.vq2_resblock_supported(32, 8) == 0
+    st = {"b.conv.1.weight": blk.conv[1].weight.detach().cpu(), "b.conv.1.bias": blk.conv[1].bias.detach().cpu(),
+          "b.conv.3.weight": blk.conv[3].weight.detach().cpu(), "b.conv.3.bias": blk.conv[3].bias.detach().cpu()}
+    x_cpu = t(rng.normal(11, f"rb.x{shape}", (n, 128, h, w)))
+    g_cpu = t(rng.normal(11, f"rb.g{shape}", (n, 128, h, w)))
+    for relu_out in (False, True):
+        for sliced in (False, True):
+            wide = torch.zeros((n, h, w, 192), device=dev)
+            xs = wide[..., 64:] if sliced else torch.empty((n, h, w, 128), device=dev)
+            xs.copy_(x_cpu.permute(0, 2, 3, 1))
+            xs.requires_grad_(True) if not sliced else None
+            xin = xs if not sliced else xs.detach().requires_grad_(True)
+            out_buf = torch.zeros((n, h, w, 160), device=dev)[..., :128] if sliced else None
+            y = blk.nhwc(xin, relu_out=relu_out, out=out_buf)
+            xr = x_cpu.clone().requires_grad_(True)
+            stp = {k: v.clone().requires_grad_(True) for k, v in st.items()}
+            ref = O.resblock(stp, "b", xr)
+            if relu_out:
+                ref = F.relu(ref)
+            close(y.permute(0, 3, 1, 2), ref, what=f"y relu_out={relu_out} sliced={sliced}")
+            for p in blk.parameters():
+                p.grad = None
+            y.backward(g_cpu.permute(0, 2, 3, 1).to(dev))
+            ref.backward(g_cpu)
+            close(xin.grad.permute(0, 3, 1, 2), xr.grad, rtol=5e-4, atol=5e-5, what="dx")
+            for name, p in (("b.conv.1.weight", blk.conv[1].weight), ("b.conv.1.bias", blk.conv[1].bias),
+                            ("b.conv.3.weight", blk.conv[3].weight), ("b.conv.3.bias", blk.conv[3].bias)):
+                gref = stp[name].grad
+                close(p.grad, gref, rtol=1e-3, atol=2e-5 * float(gref.abs().max()) + 1e-6, what=name)
+    # the unfused composition (two conv launches) stays available and agrees
+    ops.RESBLOCK_FUSED[0] = False
+    try:
+        y2 = blk.nhwc(xin.detach(), relu_out=True)
+    finally:
+        ops.RESBLOCK_FUSED[0] = True
+    close(y2, blk.nhwc(xin.detach(), relu_out=True), rtol=1e-5, atol=1e-5)

@@ -1,0 +1,291 @@
+// Fused ResBlock kernels for gfx950 (MI355X):  vqvae.py:81-96
+//
+//     r = relu(conv3x3(relu(x)) + b1)          [N,H,W,32]   (saved for the backward pass)
+//     y = [relu]( conv1x1(r) + b2 + x )        [N,H,W,128]
+//
+// as ONE launch.  The unfused path (two conv_gemm launches) re-reads every input pixel 9 times
+// through L2 -- with only 32 output channels per tile that staging, not the matrix pipe, is what
+// bounds it.  Here a workgroup owns an 8x16 pixel tile: the 10x18 halo patch of the input is staged
+// into LDS ONCE per 16-channel slice and all nine taps are fed from it by shifting the fragment
+// base address (1.4x the tensor instead of 9x, 72 MFMAs between barriers instead of 16); the 32
+// mid channels never leave the CU before the 1x1 GEMM consumes them from LDS.
+//
+//   stage 1: acc1[128 px x 32]  = sum over 8 channel slices, 9 taps, 16 ci      (v_mfma_f32_32x32x2_f32)
+//   stage 2: acc2[128 px x 128] = r_tile[128 x 32] . W2[32 x 128]  + b2 + x     (same instruction)
+//
+// Every tile is computed the same way whatever the batch size: results do not depend on N (an 8-wave
+// variant that split the depth between two wave groups was measured equal at 32x32 and dropped).
+#include "vq2_common.h"
+#include <stdlib.h>
+
+namespace vq2 {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace rb {
+constexpr unsigned RSRC_FLAGS = 0x00020000;
+constexpr int OOB = 0x7F000000;   // >= num_records of every descriptor (tensors are checked to be smaller), and
+                                  // OOB + any in-tensor slice offset does not wrap
+constexpr int TH = 8, TW = 16;            // output pixels of one workgroup
+constexpr int PW = TW + 2, PH = TH + 2;   // halo patch
+constexpr int NPATCH = PW * PH;           // 180
+constexpr int CS = 16;                    // input channels per staged slice
+constexpr int LDK = CS + 4;               // LDS row pitch (floats): conflict-free ds_read_b128 for 16 consecutive rows
+constexpr int CM = 32;                    // mid channels (n_res_channel)
+constexpr int CC = 128;                   // block channels
+constexpr int A_F4 = NPATCH * CS / 4;     // 720 float4 per activation slice
+constexpr int B_F4 = 9 * CM * CS / 4;     // 1152 float4 per weight slice
+constexpr int A_FLOATS = NPATCH * LDK;    // 3600
+constexpr int B_FLOATS = 9 * CM * LDK;    // 5760
+constexpr int LDR = CM + 4;               // pitch of the r tile and the W2 panel in LDS
+constexpr size_t LDS_BYTES = (size_t)2 * (A_FLOATS + B_FLOATS) * sizeof(float);   // 74,880: two workgroups per CU
+static_assert(128 * LDR <= 2 * (A_FLOATS + B_FLOATS), "stage-2 aliases fit in the stage-1 buffers");
+}  // namespace rb
+
+struct ResFwdParams {
+    const float *x;    // [N,H,W,ldx]
+    const float *w1;   // VQ2_PACK_FWD panel of the 3x3 weight: [32][9*128], (kh,kw,ci) with ci fastest
+    const float *b1;   // [32]
+    const float *w2;   // VQ2_PACK_FWD panel of the 1x1 weight: [128][32]
+    const float *b2;   // [128]
+    float *r;          // [N,H,W,ldr]
+    float *y;          // [N,H,W,ldy]
+    int N, H, W, ldx, ldr, ldy;
+    int tiles_x, tiles_y;
+    int relu_out;
+};
+
+__device__ __forceinline__ float4 u4_as_f4(u32x4 v) {
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+__global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const ResFwdParams P) {
+    using namespace rb;
+    constexpr int NT = 256;
+    constexpr int A_LD = (A_F4 + NT - 1) / NT;
+    constexpr int B_LD = (B_F4 + NT - 1) / NT;
+    constexpr int NS = CC / CS;          // channel slices
+    constexpr int NJ = CC / 32;          // stage-2 column blocks per wave
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                    // [2][A_FLOATS]
+    float *Bs = smem + 2 * A_FLOATS;     // [2][B_FLOATS]
+    float *Rs = smem;                    // stage 2 (aliases): r tile  [128][LDR]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wq = wave;
+    const int l31 = lane & 31, fk = 4 * (lane >> 5);
+    const int tiles = P.tiles_x * P.tiles_y;
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int n = vid / tiles;
+    const int t = vid - n * tiles;
+    const int tyi = t / P.tiles_x;
+    const int y0 = tyi * TH, x0 = (t - tyi * P.tiles_x) * TW;
+
+    const int npix = P.N * P.H * P.W;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x), 0, npix * P.ldx * 4, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rw1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.w1), 0, CM * 9 * CC * 4, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rw2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.w2), 0, CC * CM * 4, RSRC_FLAGS);
+
+    // ---- staging coordinates: float4 number f = tid + NT*j of a slice goes to LDS row f>>2, column (f&3)*4
+    int a_off[A_LD], b_off[B_LD];
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+        const int f = tid + NT * j;
+        a_off[j] = OOB;
+        if (f < A_F4) {
+            const int pp = f >> 2;
+            const int pr = pp / PW, pc = pp - pr * PW;
+            const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
+            if ((unsigned)gy < (unsigned)P.H && (unsigned)gx < (unsigned)P.W)
+                a_off[j] = ((n * P.H + gy) * P.W + gx) * P.ldx * 4 + (f & 3) * 16;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+        const int f = tid + NT * j;
+        b_off[j] = OOB;
+        if (f < B_F4) {
+            const int row = f >> 2;            // tap * 32 + co
+            b_off[j] = ((row & 31) * 9 * CC + (row >> 5) * CC) * 4 + (f & 3) * 16;
+        }
+    }
+    const int st_off = (tid >> 2) * LDK + (tid & 3) * 4;   // + (NT/4)*LDK per j
+    u32x4 ra[A_LD], rb_[B_LD];
+    auto issue_loads = [&](int s) {
+        const int soff = s * CS * 4;
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, a_off[j], soff, 0);
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) rb_[j] = __builtin_amdgcn_raw_buffer_load_b128(rw1, b_off[j], soff, 0);
+    };
+    auto store_slice = [&](int buf) {
+        float *a = As + buf * A_FLOATS + st_off;
+        float *b = Bs + buf * B_FLOATS + st_off;
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j)
+            if ((j + 1) * NT <= A_F4 || tid + NT * j < A_F4)
+                *reinterpret_cast<float4 *>(a + j * (NT / 4) * LDK) = relu4(u4_as_f4(ra[j]));   // first ReLU of the block
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j)
+            if ((j + 1) * NT <= B_F4 || tid + NT * j < B_F4)
+                *reinterpret_cast<float4 *>(b + j * (NT / 4) * LDK) = u4_as_f4(rb_[j]);
+    };
+
+    f32x16 acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+
+    // fragment bases: GEMM row i of this wave = tile pixel (2*wq + i/16, tx(i)).  The second tile row is rotated by
+    // 14 columns: its patch rows then sit at 18 + (i+14)%16 = i (mod 16) from the first row's, i.e. the 32 lanes
+    // hit the 16-byte LDS slots exactly like 32 consecutive rows do -- conflict-free ds_read_b128 for every tap.
+    const int a_frag = ((2 * wq + (l31 >> 4)) * PW + (l31 < 16 ? l31 : ((l31 + 14) & 15))) * LDK + fk;
+    const int b_frag = l31 * LDK + fk;
+    auto compute = [&](int buf) {
+        const float *a0 = As + buf * A_FLOATS + a_frag;
+        const float *b0 = Bs + buf * B_FLOATS + b_frag;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float *a = a0 + ((tap / 3) * PW + (tap % 3)) * LDK;
+            const float *b = b0 + tap * 32 * LDK;
+#pragma unroll
+            for (int k8 = 0; k8 < CS / 8; ++k8) {
+                const float4 fa = *reinterpret_cast<const float4 *>(a + 8 * k8);
+                const float4 fb = *reinterpret_cast<const float4 *>(b + 8 * k8);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc1, 0, 0, 0);
+            }
+        }
+    };
+
+    // pixel of GEMM row l31 of this wave, and per accumulator register (row = rowq + (r&3) + 8*(r>>2)) the byte
+    // offsets of that pixel in x / y at this lane's channel: column block j adds the immediate j*128
+    int pix_lane;
+    {
+        const int gy = y0 + 2 * wq + (l31 >> 4), gx = x0 + (l31 < 16 ? l31 : ((l31 + 14) & 15));
+        pix_lane = (gy < P.H && gx < P.W) ? (n * P.H + gy) * P.W + gx : -1;
+    }
+    const int rowq = 4 * (lane >> 5);
+    int xoff[16], yoff[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int pix = __shfl(pix_lane, rowq + (r & 3) + 8 * (r >> 2), 64);
+        xoff[r] = pix >= 0 ? pix * (P.ldx * 4) + l31 * 4 : OOB;
+        yoff[r] = pix >= 0 ? pix * (P.ldy * 4) + l31 * 4 : OOB;
+    }
+    f32x16 acc2[NJ];     // starts as the skip path x (vqvae.py:94); the 1x1 GEMM accumulates on top
+    float4 w2f[NJ][CM / 8];   // this lane's B fragments of the 1x1 weight, straight from L2 (16 KB panel, no LDS trip)
+
+    issue_loads(0);
+    store_slice(0);
+    __syncthreads();
+    for (int s = 0; s < NS; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < NS) {
+            issue_loads(s + 1);
+        } else {   // last slice: fetch what stage 2 needs behind the 72 MFMAs
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int k8 = 0; k8 < CM / 8; ++k8)
+                    w2f[j][k8] = u4_as_f4(__builtin_amdgcn_raw_buffer_load_b128(
+                        rw2, ((j * 32 + l31) * CM + fk + 8 * k8) * 4, 0, 0));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc2[j][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xoff[r] + j * 128, 0, 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);   // the fetches must be in flight BEFORE the 72 MFMAs, not sunk behind them
+        compute(buf);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < NS) store_slice(buf ^ 1);
+        __syncthreads();
+    }
+    // every wave is past its last fragment read: the staging buffers may be overwritten
+    {   // r = relu(acc1 + b1): to LDS for stage 2 and to HBM for the backward pass
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(P.r, 0, npix * P.ldr * 4, RSRC_FLAGS);
+        const float bv = P.b1[l31];
+        const int ldr4 = P.ldr * 4;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rowq + (r & 3) + 8 * (r >> 2);
+            const int pix = __shfl(pix_lane, row, 64);
+            const float v = fmaxf(acc1[r] + bv, 0.f);
+            Rs[(32 * wq + row) * LDR + l31] = v;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rr, pix >= 0 ? pix * ldr4 + l31 * 4 : OOB, 0, 0);
+        }
+    }
+    // a wave reads back only the 32 rows it wrote itself (LDS operations of one wave complete in order): no barrier
+
+    // ---- stage 2: 1x1 conv on the r tile, on top of x + b2
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const float bv = P.b2[j * 32 + l31];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[j][r] += bv;
+    }
+    {
+        const float *a = Rs + (32 * wq + l31) * LDR + fk;
+#pragma unroll
+        for (int k8 = 0; k8 < CM / 8; ++k8) {
+            const float4 fa = *reinterpret_cast<const float4 *>(a + 8 * k8);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float4 fb = w2f[j][k8];
+                acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc2[j], 0, 0, 0);
+                acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc2[j], 0, 0, 0);
+                acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc2[j], 0, 0, 0);
+                acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc2[j], 0, 0, 0);
+            }
+        }
+    }
+    // ---- epilogue: optional trailing ReLU (vqvae.py:122,144), store
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(P.y, 0, npix * P.ldy * 4, RSRC_FLAGS);
+    const bool relu_out = P.relu_out != 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc2[j][r];
+            if (relu_out) v = fmaxf(v, 0.f);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, yoff[r] + j * 128, 0, 0);
+        }
+}
+
+}  // namespace vq2
+
+extern "C" int vq2_resblock_supported(int32_t C, int32_t Cm) { return (C == vq2::rb::CC && Cm == vq2::rb::CM) ? 1 : 0; }
+
+extern "C" int vq2_resblock_fwd(int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cm, int flags, const float *x,
+                                int32_t ldx, const float *w1p, const float *b1, const float *w2p, const float *b2,
+                                float *r, int32_t ldr, float *y, int32_t ldy, vq2_stream_t stream) {
+    using namespace vq2;
+    VQ2_REQUIRE(N > 0 && H > 0 && W > 0, "resblock_fwd: empty tensor");
+    if (!vq2_resblock_supported(C, Cm))
+        return set_error(VQ2_ERR_UNSUPPORTED, "resblock_fwd: fused kernel is built for channel=%d, n_res_channel=%d (got %d, %d)",
+                         rb::CC, rb::CM, C, Cm);
+    VQ2_REQUIRE(x && w1p && b1 && w2p && b2 && r && y, "resblock_fwd: null pointer");
+    VQ2_REQUIRE(aligned16(x) && aligned16(w1p) && aligned16(w2p) && aligned16(r) && aligned16(y),
+                "resblock_fwd: pointers must be 16-byte aligned");
+    VQ2_REQUIRE(ldx >= C && ldy >= C && ldr >= Cm && ldx % 4 == 0 && ldy % 4 == 0 && ldr % 4 == 0,
+                "resblock_fwd: pixel strides must cover the channels and be multiples of 4");
+    VQ2_REQUIRE((flags & ~VQ2_RELU_OUT) == 0, "resblock_fwd: only VQ2_RELU_OUT is a valid flag");
+    const double npix = (double)N * H * W;
+    const int ldmax = ldx > ldy ? ldx : ldy;
+    VQ2_REQUIRE(npix * ldmax * 4.0 < (double)rb::OOB, "resblock_fwd: tensors must be smaller than %d bytes", rb::OOB);
+    ResFwdParams P{};
+    P.x = x; P.w1 = w1p; P.b1 = b1; P.w2 = w2p; P.b2 = b2; P.r = r; P.y = y;
+    P.N = N; P.H = H; P.W = W; P.ldx = ldx; P.ldr = ldr; P.ldy = ldy;
+    P.tiles_x = (W + rb::TW - 1) / rb::TW; P.tiles_y = (H + rb::TH - 1) / rb::TH;
+    P.relu_out = (flags & VQ2_RELU_OUT) != 0;
+    const int grid = N * P.tiles_x * P.tiles_y;
+    hipStream_t s = to_stream(stream);
+    const char *name = "resblock_fwd";
+    if (prof_enabled()) name = prof_label("resblock_fwd|M=%d,C=%d,Cm=%d", N * H * W, C, Cm);
+    ProfScope prof(name, 2.0 * npix * (9.0 * C * Cm + (double)Cm * C), 4.0 * npix * (2.0 * C + Cm), s);
+    allow_big_lds(resblock_fwd_kernel, rb::LDS_BYTES);
+    hipLaunchKernelGGL(resblock_fwd_kernel, dim3(grid), dim3(256), rb::LDS_BYTES, s, P);
+    return check_launch("resblock_fwd_kernel");
+}

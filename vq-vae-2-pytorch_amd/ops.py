@@ -7,6 +7,7 @@ every FLOP and every byte moved on this path is a libvq2 kernel.
 """
 from dataclasses import dataclass
 import ctypes as C
+import os
 import weakref
 
 import torch
@@ -254,6 +255,8 @@ class WgradBatch:
             self.entries[key] = ent
             self.dirty = True
         side = WGRAD_STREAM[0]
+        if side is not None and n * h * w > WGRAD_STREAM_MAX_PIXELS[0]:
+            side = None        # a launch that fills the chip by itself gains nothing from a second stream
         if side is not None:   # off the backward critical path: overlaps the next layers' data gradients
             side.wait_event(torch.cuda.current_stream().record_event())
             with torch.cuda.stream(side):
@@ -303,6 +306,7 @@ WGRAD_BATCH = [None]
 # launches and fill the SIMD slots those leave idle.  Only legal when the gradients land in arena
 # slots that nobody reads before the trainer joins the streams.
 WGRAD_STREAM = [None]
+WGRAD_STREAM_MAX_PIXELS = [int(os.environ.get("VQ2_WGRAD_STREAM_MAXPIX", str(1 << 62)))]
 
 
 def conv_wgrad(spec, x, dy, relu_in, weight, bias=None, want_dw=True, want_db=True):
@@ -471,6 +475,10 @@ def conv_op(x, weight, bias, spec, relu_in=False, relu_out=False, residual=None,
     return ConvFn.apply(x, weight, bias, residual, spec, flags, out)
 
 
+# one-launch ResBlock forward (csrc/vq2_resblock.hip) where the channel counts allow it
+RESBLOCK_FUSED = [os.environ.get("VQ2_RB_FUSED", "1") != "0"]
+
+
 class ResBlockFn(Function):
     """vqvae.py:81-96 as two launches forward and four backward:
         r = relu(conv3x3(relu(x)) + b1)            (ReLU in + ReLU out fused)
@@ -480,8 +488,19 @@ class ResBlockFn(Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, spec1, spec2, relu_out, out):
         x = as_nhwc(x)
-        r = conv_forward(spec1, x, w1, b1, VQ2_RELU_IN | VQ2_RELU_OUT)
-        y = conv_forward(spec2, r, w2, b2, VQ2_RELU_OUT if relu_out else 0, residual=x, out=out)
+        n, h, w, c = x.shape
+        if RESBLOCK_FUSED[0] and lib.vq2_resblock_supported(c, spec1.co) and spec1.k == 3 and spec2.k == 1:
+            r = torch.empty((n, h, w, spec1.co), device=x.device, dtype=torch.float32)
+            y = out if out is not None else torch.empty((n, h, w, c), device=x.device, dtype=torch.float32)
+            if tuple(y.shape) != (n, h, w, c) or not is_nhwc_dense(y):
+                raise RuntimeError("ResBlock: bad `out` buffer")
+            check(lib.vq2_resblock_fwd(n, h, w, c, spec1.co, VQ2_RELU_OUT if relu_out else 0, _p(x), ld_of(x),
+                                       _p(packed_weight(spec1, w1, PACK_FWD)), _p(b1),
+                                       _p(packed_weight(spec2, w2, PACK_FWD)), _p(b2), _p(r), ld_of(r), _p(y), ld_of(y),
+                                       _stream()), "resblock_fwd")
+        else:
+            r = conv_forward(spec1, x, w1, b1, VQ2_RELU_IN | VQ2_RELU_OUT)
+            y = conv_forward(spec2, r, w2, b2, VQ2_RELU_OUT if relu_out else 0, residual=x, out=out)
         ctx.spec1, ctx.spec2, ctx.relu_out = spec1, spec2, relu_out
         ctx.save_for_backward(x, r, w1, w2, y if relu_out else None, b1, b2)
         if out is not None:
