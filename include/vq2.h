@@ -127,18 +127,21 @@ size_t vq2_conv_wgrad_workspace_bytes(const vq2_conv_desc *d);
 int vq2_conv_wgrad(const vq2_conv_desc *d, int flags, const float *x, const float *dy, float *dw, float *db, void *ws,
                    size_t ws_bytes, vq2_stream_t stream);
 
-/* Deferred form for a whole backward pass: vq2_conv_wgrad_partial writes only the slabs (and, for a
- * conv-transpose, db), one vq2_wgrad_reduce_batched launch at the end reduces EVERY layer.  Fill one
+/* Deferred form for a whole backward pass: vq2_conv_wgrad_partial writes only the slabs and the bias
+ * partials (db != NULL asks for them; db itself is written by the reduction), one
+ * vq2_wgrad_reduce_batched launch at the end reduces EVERY layer.  Fill one
  * job per layer with vq2_wgrad_job_init (ws must stay alive and private to the layer until the batched
  * launch), set unit_offset to the running sum of n_units_w + n_units_b, upload the array once. */
 typedef struct vq2_wgrad_job {
     const float *ws;      /* the layer's slab workspace                         */
     float *dw;            /* destination, reference layout                      */
-    const float *bias_ws; /* bias partials inside ws (conv) or NULL             */
+    const float *bias_ws; /* bias partials inside ws or NULL                    */
     float *db;            /* bias gradient destination or NULL                  */
     int64_t unit_offset;  /* start of this job in the batched unit space        */
     int32_t O, I, Or, Ir, taps, S, n_units_w, n_units_b;
-    int32_t swapped, reserved; /* slab is [ci][flipped tap][co] (roles of x and dy exchanged) */
+    int32_t swapped;      /* slab is [ci][flipped tap][co] (roles of x and dy exchanged)            */
+    int32_t bias_splits;  /* > 0: bias partials are [bias_splits][I] (taken from the gathered dy
+                             operand: exchanged roles, conv-transpose); 0: [S][O]                  */
 } vq2_wgrad_job;
 int vq2_conv_wgrad_partial(const vq2_conv_desc *d, int flags, const float *x, const float *dy, float *db, void *ws,
                            size_t ws_bytes, vq2_stream_t stream);

@@ -23,7 +23,7 @@ class PackJob(C.Structure):
 class WgradJob(C.Structure):
     _fields_ = [("ws", C.c_void_p), ("dw", C.c_void_p), ("bias_ws", C.c_void_p), ("db", C.c_void_p),
                 ("unit_offset", C.c_int64)] + \
-               [(n, C.c_int32) for n in ("O", "I", "Or", "Ir", "taps", "S", "n_units_w", "n_units_b", "swapped", "reserved")]
+               [(n, C.c_int32) for n in ("O", "I", "Or", "Ir", "taps", "S", "n_units_w", "n_units_b", "swapped", "bias_splits")]
 
 
 def _load():

@@ -22,7 +22,10 @@ struct WgradParams {
     const float *g;  // grad  operand [N,Ho,Wo,ldg], O channels
     float *ws;       // [S][O][K] partial slabs
     float *bias_ws;  // [S][O] partial column sums of g (bias gradient) or null
-    int bias_from_x; // exchanged roles: bias = column sums of the CENTRE-tap block of the gathered operand; k offset of that block + 1 (0 = off)
+    int bias_taps;   // bias gradient from the GATHERED operand (it is dy: exchanged roles, conv-transpose): bit t set =
+                     // tap t visits every dy pixel exactly once over the taps of this mask; the column sums of those
+                     // k-blocks of the staged X tile are the bias gradient.  0 = bias from the G tile (plain conv)
+    int bias_nslots; // popcount(bias_taps): bias_ws is [S][nslots][I]
     int N, H, W, I, ldx;
     int Ho, Wo, O, ldg;
     int KH, KW, stride, pad;
@@ -138,8 +141,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
     }
     __syncthreads();
     const int fr = lane & 31, fk = lane >> 5;
-    const bool do_bias = P.bias_ws != nullptr && !P.bias_from_x && k0 == 0 && tid < BMO;
-    const bool do_bias_x = P.bias_ws != nullptr && P.bias_from_x && k0 == P.bias_from_x - 1 && o0 == 0 && tid < BNK;
+    const bool do_bias = P.bias_ws != nullptr && !P.bias_taps && k0 == 0 && tid < BMO;
+    int bx_col = -1;   // this thread's slot in a bias_ws row when its k column belongs to a bias tap
+    if (P.bias_ws != nullptr && P.bias_taps && o0 == 0 && tid < BNK && k0 + tid < P.K) {
+        const int tap = (k0 + tid) / P.I;
+        if ((P.bias_taps >> tap) & 1) bx_col = __popc(P.bias_taps & ((1u << tap) - 1u)) * P.I + (k0 + tid - tap * P.I);
+    }
+    const bool do_bias_x = bx_col >= 0;
     float bsum = 0.f;
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
@@ -190,7 +198,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
     }
 
     if (do_bias && o0 + tid < P.O) P.bias_ws[(size_t)split * P.O + o0 + tid] = bsum;
-    if (do_bias_x && tid < P.I) P.bias_ws[(size_t)split * P.I + tid] = bsum;
+    if (do_bias_x) P.bias_ws[(size_t)split * P.bias_nslots * P.I + bx_col] = bsum;
 
     // partial tile -> slab [split][o][k]
     float *slab = P.ws + (size_t)split * P.O * P.K;
@@ -340,10 +348,15 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
     }
     __syncthreads();
     const int fr = lane & 31, fk = lane >> 5;
-    const bool do_bias = P.bias_ws != nullptr && !P.bias_from_x && k0 == 0 && tid < BMO;
+    const bool do_bias = P.bias_ws != nullptr && !P.bias_taps && k0 == 0 && tid < BMO;
     // exchanged roles: dy is the gathered operand; its centre tap visits every pixel exactly once, so the
     // column sums of that k-block of the staged X tile are the bias gradient (tile width == one tap)
-    const bool do_bias_x = P.bias_ws != nullptr && P.bias_from_x && k0 == P.bias_from_x - 1 && o0 == 0 && tid < BNK;
+    int bx_col = -1;   // this thread's slot in a bias_ws row when its k column belongs to a bias tap
+    if (P.bias_ws != nullptr && P.bias_taps && o0 == 0 && tid < BNK && k0 + tid < P.K) {
+        const int tap = (k0 + tid) / P.I;
+        if ((P.bias_taps >> tap) & 1) bx_col = __popc(P.bias_taps & ((1u << tap) - 1u)) * P.I + (k0 + tid - tap * P.I);
+    }
+    const bool do_bias_x = bx_col >= 0;
     float bsum = 0.f;
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
@@ -393,7 +406,7 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
         __syncthreads();
     }
     if (do_bias && o0 + tid < P.O) P.bias_ws[(size_t)split * P.O + o0 + tid] = bsum;
-    if (do_bias_x && tid < P.I) P.bias_ws[(size_t)split * P.I + tid] = bsum;
+    if (do_bias_x) P.bias_ws[(size_t)split * P.bias_nslots * P.I + bx_col] = bsum;
 
     float *slab = P.ws + (size_t)split * P.O * P.K;
     const int colq = lane & 31, rowq = 4 * (lane >> 5);
@@ -420,7 +433,7 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, int O,
                                                            int I, int Or, int Ir, int taps, int S,
                                                            const float *__restrict__ bias_ws, float *__restrict__ db,
-                                                           int swapped) {
+                                                           int swapped, int bias_splits) {
     __shared__ float part[8][33];
     const int K = taps * I;
     const int total = O * K;
@@ -454,12 +467,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
         __syncthreads();
     }
     if (db && bias_ws && blockIdx.x == gridDim.x - 1) {
-        const int bstride = swapped ? I : O, blimit = swapped ? Ir : Or;
+        // bias_splits > 0: partials came from the gathered operand, [bias_splits][I]; else from the G tile, [S][O]
+        const int bstride = bias_splits ? I : O, blimit = bias_splits ? Ir : Or, bcount = bias_splits ? bias_splits : S;
         for (int base = 0; base < blimit; base += 32) {
             const int o = base + lane;
             float s0 = 0.f;
             if (o < blimit)
-                for (int z = g; z < S; z += 8) s0 += bias_ws[(size_t)z * bstride + o];
+                for (int z = g; z < bcount; z += 8) s0 += bias_ws[(size_t)z * bstride + o];
             part[g][lane] = s0;
             __syncthreads();
             if (g == 0 && o < blimit) {
@@ -492,20 +506,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const vq2_wgr
         const int lu = (int)(u - j.unit_offset);
         const bool is_bias = lu >= j.n_units_w;
         const int K = j.taps * j.I;
-        const int total = is_bias ? (j.swapped ? j.I : j.O) : j.O * K;      // stride between splits
-        const int limit = is_bias ? (j.swapped ? j.Ir : j.Or) : j.O * K;
+        const int total = is_bias ? (j.bias_splits ? j.I : j.O) : j.O * K;      // stride between splits
+        const int limit = is_bias ? (j.bias_splits ? j.Ir : j.Or) : j.O * K;
+        const int nsplit = (is_bias && j.bias_splits) ? j.bias_splits : j.S;
         const float *src = is_bias ? j.bias_ws : j.ws;
         const int t = (is_bias ? lu - j.n_units_w : lu) * 32 + lane;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         if (t < limit) {
             int z = g;
-            for (; z + 24 < j.S; z += 32) {
+            for (; z + 24 < nsplit; z += 32) {
                 s0 += src[(size_t)z * total + t];
                 s1 += src[(size_t)(z + 8) * total + t];
                 s2 += src[(size_t)(z + 16) * total + t];
                 s3 += src[(size_t)(z + 24) * total + t];
             }
-            for (; z < j.S; z += 8) s0 += src[(size_t)z * total + t];
+            for (; z < nsplit; z += 8) s0 += src[(size_t)z * total + t];
         }
         part[g][lane] = (s0 + s1) + (s2 + s3);
         __syncthreads();
@@ -576,6 +591,21 @@ static WgradPlan plan_wgrad(const vq2_conv_desc *d) {
     p.S = (p.M + rps - 1) / rps;
     p.rows_per_split = rps;
     return p;
+}
+
+// Which taps of the gathered operand cover every dy pixel exactly once (bias gradient = their column sums):
+// exchanged roles -> the centre tap (its own flip); conv-transpose k4 s2 p1 -> taps (1,1),(1,2),(2,1),(2,2),
+// one per output phase, never out of bounds.
+static void bias_taps_of(const vq2_conv_desc *d, const WgradPlan &p, int &taps, int &nslots) {
+    taps = 0; nslots = 0;
+    if (p.swapped) { taps = 1 << ((d->KH / 2) * d->KW + d->KW / 2); nslots = 1; }
+    else if (d->transposed) { taps = (1 << 5) | (1 << 6) | (1 << 9) | (1 << 10); nslots = 4; }
+}
+
+static size_t bias_ws_floats(const vq2_conv_desc *d, const WgradPlan &p) {
+    int taps, nslots;
+    bias_taps_of(d, p, taps, nslots);
+    return taps ? (size_t)p.S * nslots * p.I : (size_t)p.S * p.O;
 }
 
 template <int WAVES_M, int WAVES_N, int MT, int NT>
@@ -677,7 +707,7 @@ using namespace vq2;
 extern "C" size_t vq2_conv_wgrad_workspace_bytes(const vq2_conv_desc *d) {
     if (!d || d->N <= 0 || d->Ci <= 0 || d->Co <= 0) return 0;
     const WgradPlan p = plan_wgrad(d);
-    return (size_t)p.S * p.O * (p.K + 1) * sizeof(float) + vq2_colsum_workspace_bytes((int64_t)d->N * 4 * d->H * d->W, d->Co);
+    return ((size_t)p.S * p.O * p.K + bias_ws_floats(d, p)) * sizeof(float);
 }
 
 // slabs (+ bias partials); reduce == true also runs the per-layer reduction into dw/db
@@ -697,15 +727,9 @@ static int wgrad_impl(const vq2_conv_desc *d, int flags, const float *x, const f
     VQ2_REQUIRE(ws_bytes >= vq2_conv_wgrad_workspace_bytes(d), "conv_wgrad: workspace too small");
     WgradParams P{};
     P.ws = static_cast<float *>(ws);
-    float *bias_ws = P.ws + (size_t)p.S * p.O * p.K;       // [S][O] bias partials (conv only)
-    float *colsum_ws = bias_ws + (size_t)p.S * p.O;        // convT: separate column-sum pass over dy
-    P.bias_ws = (db && !d->transposed && !p.swapped) ? bias_ws : nullptr;
-    P.bias_from_x = 0;
-    const bool bias_x = db && p.swapped && p.bnk == p.I;   // one tap per k-tile
-    if (bias_x) {
-        P.bias_ws = bias_ws;
-        P.bias_from_x = ((d->KH / 2) * d->KW + d->KW / 2) * p.I + 1;   // the centre tap is its own flip
-    }
+    float *bias_ws = P.ws + (size_t)p.S * p.O * p.K;       // bias partials: [S][O], or [S][nslots][I] from the gathered operand
+    bias_taps_of(d, p, P.bias_taps, P.bias_nslots);
+    P.bias_ws = db ? bias_ws : nullptr;
     P.KH = d->KH; P.KW = d->KW; P.stride = d->stride; P.pad = d->pad;
     P.O = p.O; P.I = p.I; P.K = p.K; P.M = p.M; P.rows_per_split = p.rows_per_split;
     P.N = d->N;
@@ -743,26 +767,15 @@ static int wgrad_impl(const vq2_conv_desc *d, int flags, const float *x, const f
     else if (p.bmo == 128) e = launch_wgrad<4, 1, 1, 1>(P, p.S, s);     // 128 x 32 (1x1 convs with few inputs)
     else e = launch_wgrad<2, 2, 1, 1>(P, p.S, s);                       // 64 x 64
     if (e) return e;
-    if (!reduce) {
-        const int cor2 = d->Cor ? d->Cor : d->Co;
-        if (db && d->transposed) return colsum_impl(dy, (int64_t)d->N * 4 * d->H * d->W, d->Co, d->ldy, db, cor2, colsum_ws, s);
-        if (db && p.swapped && !bias_x) return colsum_impl(dy, (int64_t)p.M, d->Co, d->ldy, db, cor2, colsum_ws, s);
-        return VQ2_OK;
-    }
+    if (!reduce) return VQ2_OK;
     const int total = p.O * p.K;
     const int blocks = (total + 31) / 32 < 4096 ? (total + 31) / 32 : 4096;
     const int cir = d->Cir ? d->Cir : d->Ci, cor = d->Cor ? d->Cor : d->Co;
     const bool sw = d->transposed || p.swapped;
     const int Or = sw ? cir : cor, Ir = sw ? cor : cir;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, P.ws, dw, p.O, p.I, Or, Ir, d->KH * d->KW,
-                       p.S, P.bias_ws, db, p.swapped);
-    if (int e2 = check_launch("wgrad_reduce_kernel")) return e2;
-    if (db && p.swapped && !bias_x) return colsum_impl(dy, (int64_t)p.M, d->Co, d->ldy, db, cor, colsum_ws, s);
-    if (db && d->transposed) {  // bias gradient of a conv-transpose = column sums of dy [N,2H,2W,Co]
-        const int64_t rows = (int64_t)d->N * 4 * d->H * d->W;
-        return colsum_impl(dy, rows, d->Co, d->ldy, db, cor, colsum_ws, s);
-    }
-    return VQ2_OK;
+                       p.S, P.bias_ws, db, p.swapped, P.bias_taps ? p.S * P.bias_nslots : 0);
+    return check_launch("wgrad_reduce_kernel");
 }
 
 extern "C" int vq2_conv_wgrad(const vq2_conv_desc *d, int flags, const float *x, const float *dy, float *dw, float *db,
@@ -783,14 +796,16 @@ extern "C" int vq2_wgrad_job_init(const vq2_conv_desc *d, const void *ws, float 
     job->ws = w; job->dw = dw; job->db = nullptr; job->bias_ws = nullptr;
     const bool sw = d->transposed || p.swapped;
     job->O = p.O; job->I = p.I; job->Or = sw ? cir : cor; job->Ir = sw ? cor : cir;
-    job->swapped = p.swapped; job->reserved = 0;
+    job->swapped = p.swapped; job->bias_splits = 0;
     job->taps = d->KH * d->KW; job->S = p.S;
     job->n_units_w = (p.O * p.K + 31) / 32;
     job->n_units_b = 0;
-    const bool bias_x = db && p.swapped && p.bnk == p.I;
-    if (db && !d->transposed && (!p.swapped || bias_x)) {   // the other cases produce db in the partial call itself
+    if (db) {
+        int taps, nslots;
+        bias_taps_of(d, p, taps, nslots);
         job->db = db; job->bias_ws = w + (size_t)p.S * p.O * p.K;
-        job->n_units_b = ((p.swapped ? job->Ir : job->Or) + 31) / 32;
+        job->bias_splits = taps ? p.S * nslots : 0;
+        job->n_units_b = ((taps ? job->Ir : job->Or) + 31) / 32;
     }
     job->unit_offset = 0;
     return VQ2_OK;
