@@ -334,8 +334,10 @@ extern "C" int vq2_vq_fwd(const float *x, int32_t ldx, const float *embed, const
     if (int e = check_launch("vq_fwd_kernel")) return e;
     if (counts) {
         VQ2_REQUIRE(K <= 16384, "vq_fwd: n_embed > 16384 not supported by the histogram kernel");
-        const int hb = (int)((M + 256 * 64 - 1) / (256 * 64));  // >= 64 indices per thread
-        hipLaunchKernelGGL(vq_hist_kernel, dim3(hb < 1 ? 1 : (hb > 128 ? 128 : hb)), dim3(256), (size_t)K * sizeof(int), s,
+        // same-bin LDS atomics of a wave serialise (collapsed codebooks: all 64 lanes on one bin), so the
+        // histogram wants many short workgroups, not few long ones: 4-8 indices per thread
+        const int hb = (int)((M + 256 * 4 - 1) / (256 * 4));
+        hipLaunchKernelGGL(vq_hist_kernel, dim3(hb < 1 ? 1 : (hb > 256 ? 256 : hb)), dim3(256), (size_t)K * sizeof(int), s,
                            idx, M, K, counts);
         return check_launch("vq_hist_kernel");
     }

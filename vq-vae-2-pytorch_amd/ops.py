@@ -434,11 +434,34 @@ class ReluFn(Function):
 
 
 # ----------------------------------------------------------------------------- fused conv op
+class GradStash:
+    """Side channel for a tensor that is consumed twice (enc_b -> enc_t and the concat, vqvae.py:225,233):
+    the consumer that back-propagates FIRST (CatViewFn) parks its gradient here instead of returning it,
+    the one that runs LAST (the first conv of enc_t) adds it in its dgrad epilogue -- the sum autograd would
+    form with a separate add kernel (+ a slice copy) happens inside a launch that exists anyway.  Either
+    order is correct: a stash that was already taken refuses the put and the gradient flows normally."""
+
+    def __init__(self):
+        self.tensor = None
+        self.closed = False
+
+    def put(self, t):
+        if self.closed:
+            return False
+        self.tensor = t
+        return True
+
+    def take(self):
+        t, self.tensor, self.closed = self.tensor, None, True
+        return t
+
+
 class ConvFn(Function):
     """y = [relu]( conv|convT([relu] x) + b [+ residual] ), NHWC."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, spec, flags, out):
+    def forward(ctx, x, weight, bias, residual, spec, flags, out, grad_stash=None):
+        ctx.grad_stash = grad_stash
         x = as_nhwc(x)
         if residual is not None:
             residual = as_nhwc(residual)
@@ -461,18 +484,22 @@ class ConvFn(Function):
         relu_in = bool(flags & VQ2_RELU_IN)
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
-            dx = conv_dgrad(spec, x.shape, g, weight, mask=x if relu_in else None)
+            other = ctx.grad_stash.take() if ctx.grad_stash is not None else None   # gradient of x's second consumer
+            dx = conv_dgrad(spec, x.shape, g, weight, mask=x if relu_in else None, residual=other)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = conv_wgrad(spec, x, g, relu_in, weight, bias, ctx.needs_input_grad[1],
                                 ctx.has_bias and ctx.needs_input_grad[2])
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = g
-        return dx, dw, db, dres, None, None, None
+        return dx, dw, db, dres, None, None, None, None
 
 
-def conv_op(x, weight, bias, spec, relu_in=False, relu_out=False, residual=None, out=None):
+def conv_op(x, weight, bias, spec, relu_in=False, relu_out=False, residual=None, out=None, grad_stash=None):
     flags = (VQ2_RELU_IN if relu_in else 0) | (VQ2_RELU_OUT if relu_out else 0)
-    return ConvFn.apply(x, weight, bias, residual, spec, flags, out)
+    if grad_stash is not None and relu_in:
+        grad_stash.closed = True      # the epilogue masks before it adds: only a conv without input ReLU can take it
+        grad_stash = None
+    return ConvFn.apply(x, weight, bias, residual, spec, flags, out, grad_stash)
 
 
 # one-launch ResBlock forward (csrc/vq2_resblock.hip) where the channel counts allow it
@@ -528,14 +555,18 @@ class CatViewFn(Function):
     of `buf` (vqvae.py:218,233): forward is free, backward hands out slices of the gradient."""
 
     @staticmethod
-    def forward(ctx, a, b, buf):
+    def forward(ctx, a, b, buf, stash=None):
         ctx.ca = a.shape[3]
+        ctx.stash = stash
         return buf.view_as(buf)
 
     @staticmethod
     def backward(ctx, g):
         g = as_nhwc(g)
-        return g[..., :ctx.ca], g[..., ctx.ca:], None
+        gb = g[..., ctx.ca:]
+        if ctx.stash is not None and ctx.stash.put(gb):
+            gb = None      # b's other consumer adds it inside its own dgrad launch (GradStash)
+        return g[..., :ctx.ca], gb, None, None
 
 
 class FanOutFn(Function):
@@ -613,6 +644,7 @@ class QuantizeFn(Function):
         check(lib.vq2_vq_loss(_p(part), m, d, _p(diff), _stream()), "vq_loss")
         ctx.save_for_backward(x, idx, embed_t)
         ctx.k = k
+        ctx.set_materialize_grads(False)   # no zero-filled gradients for idx / stats (two fill launches per call)
         ctx.mark_non_differentiable(idx)
         if stats is not None:
             ctx.mark_non_differentiable(stats)
@@ -622,6 +654,8 @@ class QuantizeFn(Function):
     def backward(ctx, g_out, g_diff, _gi, _gs):
         x, idx, embed_t = ctx.saved_tensors
         n, h, w, d = x.shape
+        if g_out is None and g_diff is None:
+            return None, None, None, None, None
         if g_out is not None:
             g_out = as_nhwc(g_out)
         if g_diff is not None and not g_diff.is_contiguous():
@@ -687,6 +721,33 @@ def mse_loss(a, b):
     return MseLossFn.apply(a, b)
 
 
+def stage1_loss_and_seeds(dec, diff, img, weight, denom):
+    """Trainer fast path of Stage1LossFn: the loss values AND the gradients of (dec, diff) for a backward
+    seed of exactly 1 (what loss.backward() means), so the pass can start with
+    torch.autograd.backward((dec, diff), seeds) -- no ones_like fill, no gradient re-scaling launches.
+    Returns (loss, recon, latent, d_dec, d_diff)."""
+    dc, ic = dec.detach(), img.detach()
+    if not (dc.is_contiguous() and ic.is_contiguous()) or diff.numel() != 1:
+        raise RuntimeError("stage1_loss_and_seeds: contiguous dec/img and the [1]-shaped latent loss expected")
+    n = dc.numel()
+    recon = torch.empty((), device=dc.device, dtype=torch.float32)
+    grad = torch.empty_like(dc)
+    ws = torch.empty(lib.vq2_mse_workspace_bytes(n) // 4, device=dc.device, dtype=torch.float32)
+    check(lib.vq2_mse_fwd_bwd(_p(dc), _p(ic), n, int(denom), None, _p(recon), _p(grad), _p(ws), ws.numel() * 4,
+                              _stream()), "mse_fwd_bwd")
+    latent = diff.detach().reshape(())
+    loss = torch.empty((), device=dc.device, dtype=torch.float32)
+    check(lib.vq2_axpby(_p(recon), _p(latent), float(weight), _p(loss), 1, _stream()), "axpby")
+    key = (dc.device, float(weight), tuple(diff.shape))
+    seed = _DIFF_SEEDS.get(key)
+    if seed is None:
+        seed = _DIFF_SEEDS[key] = torch.full(tuple(diff.shape), float(weight), device=dc.device, dtype=torch.float32)
+    return loss, recon, latent, grad, seed
+
+
+_DIFF_SEEDS = {}
+
+
 class Stage1LossFn(Function):
     """loss = MSE(dec, img) + 0.25 * diff.mean()  (train_vqvae.py:83-85) -> (loss, recon, latent)."""
 
@@ -711,12 +772,15 @@ class Stage1LossFn(Function):
         ctx.save_for_backward(grad)
         ctx.weight = weight
         ctx.diff_shape = diff.shape
+        ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(recon, latent)
         return loss, recon, latent
 
     @staticmethod
     def backward(ctx, g, _gr, _gl):
         (grad,) = ctx.saved_tensors
+        if g is None:
+            return None, None, None, None, None
         d_dec = None if grad is None else _scale_by(grad, g)
         d_diff = _scale_by(torch.ones(ctx.diff_shape, device=g.device), g, ctx.weight) if ctx.needs_input_grad[1] else None
         return d_dec, d_diff, None, None, None

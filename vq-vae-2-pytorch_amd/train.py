@@ -81,15 +81,17 @@ class Stage1Trainer:
             # reconstruction or of its gradient (the zero pad lane contributes nothing)
             x = ops.to_nhwc(img)
             dec, diff = model.forward_nhwc(x)
-            loss, recon, latent = ops.Stage1LossFn.apply(dec, diff, x, LATENT_LOSS_WEIGHT, img.numel())
+            loss, recon, latent, d_dec, d_diff = ops.stage1_loss_and_seeds(dec, diff, x, LATENT_LOSS_WEIGHT, img.numel())
+            roots, seeds = (dec, diff), (d_dec, d_diff)
         else:
             dec, diff = model(img)
             loss, recon, latent = stage1_loss(dec, diff, img)
+            roots, seeds = (loss,), (None,)
         self._late_seen, self._bucket_sent = 0, False
         ops.WGRAD_STREAM[0] = self.wgrad_stream
         ops.WGRAD_BATCH[0] = self.wgrad_batch
         try:
-            loss.backward()
+            torch.autograd.backward(roots, seeds)
         finally:
             ops.WGRAD_STREAM[0] = None
             ops.WGRAD_BATCH[0] = None

@@ -43,8 +43,8 @@ class _ConvBase(nn.Module):
         bound = 1 / math.sqrt(fan_in)
         nn.init.uniform_(self.bias, -bound, bound)
 
-    def nhwc(self, x, relu_in=False, relu_out=False, residual=None, out=None):
-        return ops.conv_op(x, self.weight, self.bias, self.spec, relu_in, relu_out, residual, out)
+    def nhwc(self, x, relu_in=False, relu_out=False, residual=None, out=None, grad_stash=None):
+        return ops.conv_op(x, self.weight, self.bias, self.spec, relu_in, relu_out, residual, out, grad_stash)
 
     def forward(self, input):
         return ops.from_nhwc(self.nhwc(ops.to_nhwc(input)), self.spec.cout)
@@ -153,7 +153,7 @@ class ResBlock(nn.Module):
         return ops.from_nhwc(self.nhwc(ops.to_nhwc(input)), input.shape[1])
 
 
-def _run_blocks(blocks, x, out=None):
+def _run_blocks(blocks, x, out=None, grad_stash=None):
     """Execute an nn.Sequential of {Conv2d, ConvTranspose2d, ReLU, ResBlock} with every ReLU fused
     into the conv that follows it (or, for a trailing ReLU, the op that precedes it)."""
     plan = []
@@ -182,8 +182,12 @@ def _run_blocks(blocks, x, out=None):
             x = ops.ReluFn.apply(x)
             if last and out is not None:
                 raise NotImplementedError("trailing stand-alone ReLU cannot target an output slice")
+        elif i == 0 and grad_stash is not None and isinstance(m, _ConvBase):
+            x = m.nhwc(x, relu_in=rin, relu_out=rout, out=out if last else None, grad_stash=grad_stash)
         else:
             x = m.nhwc(x, relu_in=rin, relu_out=rout, out=out if last else None)
+    if grad_stash is not None and not (plan and isinstance(plan[0][0], _ConvBase)):
+        grad_stash.closed = True   # nobody will take it: the gradient has to flow the ordinary way
     return x
 
 
@@ -212,8 +216,8 @@ class Encoder(nn.Module):
         self.blocks = nn.Sequential(*blocks)
         self.out_channels = channel
 
-    def nhwc(self, x, out=None):
-        return _run_blocks(self.blocks, x, out)
+    def nhwc(self, x, out=None, grad_stash=None):
+        return _run_blocks(self.blocks, x, out, grad_stash)
 
     def forward(self, input):
         return ops.from_nhwc(self.nhwc(ops.to_nhwc(input)), self.out_channels)
@@ -279,12 +283,14 @@ class VQVAE(nn.Module):
             raise RuntimeError("VQVAE: input height/width must be multiples of 8")
         cat = torch.empty((n, h // 4, w // 4, e + c), device=x.device, dtype=torch.float32)
         enc_b = self.enc_b.nhwc(x, out=cat[..., e:])
-        enc_b_for_t, enc_b_for_cat = ops.FanOutFn.apply(enc_b)
-        enc_t = self.enc_t.nhwc(enc_b_for_t)
+        # enc_b feeds enc_t AND the concat (vqvae.py:225,233): the concat's gradient slice is added inside
+        # the dgrad launch of enc_t's first conv (ops.GradStash) instead of by an add kernel
+        skip = ops.GradStash() if torch.is_grad_enabled() else None
+        enc_t = self.enc_t.nhwc(enc_b, grad_stash=skip)
         quant_t, diff_t, id_t = self.quantize_t(self.quantize_conv_t.nhwc(enc_t))
         quant_t_for_dec, quant_t_ret = ops.FanOutFn.apply(quant_t)
         dec_t = self.dec_t.nhwc(quant_t_for_dec, out=cat[..., :e])
-        enc_cat = ops.CatViewFn.apply(dec_t, enc_b_for_cat, cat)
+        enc_cat = ops.CatViewFn.apply(dec_t, enc_b, cat, skip)
         quant_b, diff_b, id_b = self.quantize_b(self.quantize_conv_b.nhwc(enc_cat), _out=quant_b_out)
         diff = ops.AddScalarsFn.apply(diff_t, diff_b)
         return quant_t_ret, quant_b, diff, id_t, id_b
