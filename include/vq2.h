@@ -119,6 +119,13 @@ int vq2_resblock_fwd(int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cm, int
  * stride lddx; dy has pixel stride d->ldy. */
 int vq2_conv_dgrad(const vq2_conv_desc *d, const float *dy, const float *wp, const float *mask, int32_t ldmask,
                    const float *residual, int32_t ldres, float *dx, int32_t lddx, vq2_stream_t stream);
+/* Same with flags.  VQ2_MASK_AFTER_RESIDUAL: dx = (dgrad(dy) + residual) * (mask > 0) -- x is itself the
+ * output of a fused trailing ReLU (vqvae.py:122,144) whose backward mask is applied to the COMPLETE
+ * gradient here (residual = the gradient of x's other consumer), instead of by a vq2_relu_bwd pass. */
+#define VQ2_MASK_AFTER_RESIDUAL 4
+int vq2_conv_dgrad_ex(const vq2_conv_desc *d, int flags, const float *dy, const float *wp, const float *mask,
+                      int32_t ldmask, const float *residual, int32_t ldres, float *dx, int32_t lddx,
+                      vq2_stream_t stream);
 
 /* dw (reference layout, OIHW or IOHW) = wgrad([relu]x, dy) and, if db != NULL, db[Cor] = sum over
  * pixels of dy (bias gradient, fused).  Deterministic split-K: partial slabs in `ws`, then an

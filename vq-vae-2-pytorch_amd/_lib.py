@@ -45,6 +45,7 @@ def _load():
         "vq2_pack_weights_batched": (C.c_int, [P, I32, I64, P]),
         "vq2_conv_fwd": (C.c_int, [DP, C.c_int, P, P, P, P, I32, P, P]),
         "vq2_conv_dgrad": (C.c_int, [DP, P, P, P, I32, P, I32, P, I32, P]),
+        "vq2_conv_dgrad_ex": (C.c_int, [DP, C.c_int, P, P, P, I32, P, I32, P, I32, P]),
         "vq2_conv_wgrad_workspace_bytes": (SZ, [DP]),
         "vq2_conv_wgrad": (C.c_int, [DP, C.c_int, P, P, P, P, P, SZ, P]),
         "vq2_conv_wgrad_partial": (C.c_int, [DP, C.c_int, P, P, P, P, SZ, P]),

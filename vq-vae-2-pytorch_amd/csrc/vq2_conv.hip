@@ -39,6 +39,7 @@ struct ConvGemmParams {
     int Hy, Wy;           // real output image size
     int ldm, ldr;
     int relu_in, relu_out;
+    int mask_after;       // apply the mask to (acc + residual) instead of to acc alone
     int nbias;            // bias has nbias entries (real output channels)
     double flops, bytes;  // algorithmic work of this launch (for the profiler only)
     unsigned long long *stamps;  // diagnostic build only (STAMP): per-phase cycle totals of workgroup 0
@@ -269,8 +270,9 @@ __global__ __launch_bounds__(256, (MT * NT == 4) ? (BK == 16 ? 3 : 2) : 1) void 
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     float v = acc[i][j][rb + q] + bv;
-                    if (maskp) v = (mk[q] > 0.f) ? v : 0.f;
+                    if (maskp && !P.mask_after) v = (mk[q] > 0.f) ? v : 0.f;
                     if (resp) v += rs[q];
+                    if (maskp && P.mask_after) v = (mk[q] > 0.f) ? v : 0.f;
                     if (P.relu_out) v = fmaxf(v, 0.f);
                     if (ok[q]) yp[(size_t)pix[q] * P.ldy + co] = v;
                 }
@@ -493,6 +495,7 @@ __global__ __launch_bounds__(256, (MT * NT == 4) ? (BK == 16 ? 3 : 2) : 1) void 
     const __amdgpu_buffer_rsrc_t rrs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.res ? P.res : P.y), 0, P.res ? ybytes * P.ldr : 0, RSRC_FLAGS);
     const bool has_mask = P.mask != nullptr, has_res = P.res != nullptr;
+    const bool mask_first = has_mask && !P.mask_after, mask_last = has_mask && P.mask_after;
     const int colq = lane & 31;
     const int rowq = 4 * (lane >> 5);
     const int ldy4 = P.ldy * 4, ldm4 = P.ldm * 4, ldr4 = P.ldr * 4;
@@ -545,8 +548,9 @@ __global__ __launch_bounds__(256, (MT * NT == 4) ? (BK == 16 ? 3 : 2) : 1) void 
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     float v = acc[i][j][rb8 + q] + bv;
-                    if (has_mask) v = (mk[q] > 0.f) ? v : 0.f;
+                    if (mask_first) v = (mk[q] > 0.f) ? v : 0.f;
                     if (has_res) v += rs[q];
+                    if (mask_last) v = (mk[q] > 0.f) ? v : 0.f;
                     if (P.relu_out) v = fmaxf(v, 0.f);
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, pix[q] >= 0 ? pix[q] * ldy4 + co4 : OOB, 0, 0);
                 }
@@ -917,7 +921,14 @@ extern "C" int vq2_conv_fwd(const vq2_conv_desc *d, int flags, const float *x, c
 extern "C" int vq2_conv_dgrad(const vq2_conv_desc *d, const float *dy, const float *wp, const float *mask,
                               int32_t ldmask, const float *residual, int32_t ldres, float *dx, int32_t lddx,
                               vq2_stream_t stream) {
+    return vq2_conv_dgrad_ex(d, 0, dy, wp, mask, ldmask, residual, ldres, dx, lddx, stream);
+}
+
+extern "C" int vq2_conv_dgrad_ex(const vq2_conv_desc *d, int flags, const float *dy, const float *wp, const float *mask,
+                                 int32_t ldmask, const float *residual, int32_t ldres, float *dx, int32_t lddx,
+                                 vq2_stream_t stream) {
     if (int e = check_desc(d)) return e;
+    VQ2_REQUIRE((flags & ~VQ2_MASK_AFTER_RESIDUAL) == 0, "conv_dgrad: unknown flag");
     VQ2_REQUIRE(dy && wp && dx, "conv_dgrad: null pointer");
     VQ2_REQUIRE(aligned16(dy) && aligned16(wp) && aligned16(dx), "conv_dgrad: pointers must be 16-byte aligned");
     VQ2_REQUIRE(lddx >= d->Ci && lddx % 4 == 0, "conv_dgrad: lddx=%d must be >= Ci and a multiple of 4", lddx);
@@ -930,6 +941,7 @@ extern "C" int vq2_conv_dgrad(const vq2_conv_desc *d, const float *dy, const flo
     P.N = d->N; P.H = Hy; P.W = Wy; P.Ci = d->Co; P.ldx = d->ldy;
     P.Co = d->Ci; P.ldy = lddx; P.ldm = ldmask; P.ldr = ldres;
     P.relu_in = 0; P.relu_out = 0;
+    P.mask_after = (flags & VQ2_MASK_AFTER_RESIDUAL) != 0;
     P.Hy = d->H; P.Wy = d->W;
     if (!d->transposed && d->stride == 1) {
         // full correlation with the flipped kernel: pad' = KH-1-pad

@@ -17,6 +17,7 @@ from ._lib import lib, check, ConvDesc, PackJob, WgradJob
 
 VQ2_RELU_IN = 1
 VQ2_RELU_OUT = 2
+VQ2_MASK_AFTER_RESIDUAL = 4
 PACK_FWD = 0
 PACK_DGRAD = 1
 
@@ -208,15 +209,16 @@ def conv_forward(spec, x, weight, bias, flags=0, residual=None, out=None):
     return out
 
 
-def conv_dgrad(spec, xshape, dy, weight, mask=None, residual=None, out=None):
+def conv_dgrad(spec, xshape, dy, weight, mask=None, residual=None, out=None, mask_after=False):
     n, h, w, _ = xshape
     if out is None:
         out = torch.empty((n, h, w, spec.ci), device=dy.device, dtype=torch.float32)
     d = _desc(spec, n, h, w, spec.ci, ld_of(dy))
     wp = packed_weight(spec, weight, PACK_DGRAD)
-    check(lib.vq2_conv_dgrad(C.byref(d), _p(dy), _p(wp), _p(mask), ld_of(mask) if mask is not None else 0,
-                             _p(residual), ld_of(residual) if residual is not None else 0, _p(out), ld_of(out),
-                             _stream()), "conv_dgrad")
+    check(lib.vq2_conv_dgrad_ex(C.byref(d), VQ2_MASK_AFTER_RESIDUAL if mask_after else 0, _p(dy), _p(wp), _p(mask),
+                                ld_of(mask) if mask is not None else 0, _p(residual),
+                                ld_of(residual) if residual is not None else 0, _p(out), ld_of(out), _stream()),
+          "conv_dgrad")
     return out
 
 
@@ -441,9 +443,10 @@ class GradStash:
     form with a separate add kernel (+ a slice copy) happens inside a launch that exists anyway.  Either
     order is correct: a stash that was already taken refuses the put and the gradient flows normally."""
 
-    def __init__(self):
+    def __init__(self, strict=False):
         self.tensor = None
         self.closed = False
+        self.strict = strict   # the taker also applies a ReLU mask to the sum: falling back would be wrong, so raise
 
     def put(self, t):
         if self.closed:
@@ -460,8 +463,11 @@ class ConvFn(Function):
     """y = [relu]( conv|convT([relu] x) + b [+ residual] ), NHWC."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, spec, flags, out, grad_stash=None):
-        ctx.grad_stash = grad_stash
+    def forward(ctx, x, weight, bias, residual, spec, flags, out, grad_stash=None, mask_input=False, premasked=False):
+        """mask_input: x is the output of a fused trailing ReLU and this op is the one that applies that ReLU's
+        backward mask (to its complete input gradient); premasked: the consumers of y do the same for this op's
+        own VQ2_RELU_OUT, so the incoming gradient is already masked."""
+        ctx.grad_stash, ctx.mask_input, ctx.premasked = grad_stash, mask_input, premasked
         x = as_nhwc(x)
         if residual is not None:
             residual = as_nhwc(residual)
@@ -479,27 +485,29 @@ class ConvFn(Function):
         x, weight, y, bias = ctx.saved_tensors
         spec, flags = ctx.spec, ctx.flags
         g = as_nhwc(dy)
-        if flags & VQ2_RELU_OUT:
+        if (flags & VQ2_RELU_OUT) and not ctx.premasked:
             g = relu_bwd(g, y)
         relu_in = bool(flags & VQ2_RELU_IN)
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
             other = ctx.grad_stash.take() if ctx.grad_stash is not None else None   # gradient of x's second consumer
-            dx = conv_dgrad(spec, x.shape, g, weight, mask=x if relu_in else None, residual=other)
+            dx = conv_dgrad(spec, x.shape, g, weight, mask=x if (relu_in or ctx.mask_input) else None, residual=other,
+                            mask_after=ctx.mask_input)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = conv_wgrad(spec, x, g, relu_in, weight, bias, ctx.needs_input_grad[1],
                                 ctx.has_bias and ctx.needs_input_grad[2])
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = g
-        return dx, dw, db, dres, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None
 
 
-def conv_op(x, weight, bias, spec, relu_in=False, relu_out=False, residual=None, out=None, grad_stash=None):
+def conv_op(x, weight, bias, spec, relu_in=False, relu_out=False, residual=None, out=None, grad_stash=None,
+            mask_input=False, premasked=False):
     flags = (VQ2_RELU_IN if relu_in else 0) | (VQ2_RELU_OUT if relu_out else 0)
-    if grad_stash is not None and relu_in:
-        grad_stash.closed = True      # the epilogue masks before it adds: only a conv without input ReLU can take it
+    if grad_stash is not None and relu_in and not mask_input:
+        grad_stash.closed = True      # the epilogue would mask before it adds
         grad_stash = None
-    return ConvFn.apply(x, weight, bias, residual, spec, flags, out, grad_stash)
+    return ConvFn.apply(x, weight, bias, residual, spec, flags, out, grad_stash, mask_input, premasked)
 
 
 # one-launch ResBlock forward (csrc/vq2_resblock.hip) where the channel counts allow it
@@ -513,7 +521,8 @@ class ResBlockFn(Function):
     backward fuses both ReLU masks and the skip-path add into the dgrad epilogues."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, spec1, spec2, relu_out, out):
+    def forward(ctx, x, w1, b1, w2, b2, spec1, spec2, relu_out, out, premasked=False):
+        ctx.premasked = premasked
         x = as_nhwc(x)
         n, h, w, c = x.shape
         if RESBLOCK_FUSED[0] and lib.vq2_resblock_supported(c, spec1.co) and spec1.k == 3 and spec2.k == 1:
@@ -539,7 +548,7 @@ class ResBlockFn(Function):
         x, r, w1, w2, y, b1, b2 = ctx.saved_tensors
         s1, s2 = ctx.spec1, ctx.spec2
         g = as_nhwc(dy)
-        if ctx.relu_out:
+        if ctx.relu_out and not ctx.premasked:
             g = relu_bwd(g, y)
         # through conv1x1 and the inner ReLU (mask r > 0)
         dh = conv_dgrad(s2, r.shape, g, w2, mask=r)
@@ -547,7 +556,7 @@ class ResBlockFn(Function):
         # through conv3x3 and the outer ReLU (mask x > 0), plus the skip gradient
         dx = conv_dgrad(s1, x.shape, dh, w1, mask=x, residual=g) if ctx.needs_input_grad[0] else None
         dw1, db1 = conv_wgrad(s1, x, dh, True, w1, b1, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
-        return dx, dw1, db1, dw2, db2, None, None, None, None
+        return dx, dw1, db1, dw2, db2, None, None, None, None, None
 
 
 class CatViewFn(Function):
@@ -564,8 +573,11 @@ class CatViewFn(Function):
     def backward(ctx, g):
         g = as_nhwc(g)
         gb = g[..., ctx.ca:]
-        if ctx.stash is not None and ctx.stash.put(gb):
-            gb = None      # b's other consumer adds it inside its own dgrad launch (GradStash)
+        if ctx.stash is not None:
+            if ctx.stash.put(gb):
+                gb = None      # b's other consumer adds it inside its own dgrad launch (GradStash)
+            elif ctx.stash.strict:
+                raise RuntimeError("GradStash: the consumer that applies b's ReLU mask ran before this gradient arrived")
         return g[..., :ctx.ca], gb, None, None
 
 

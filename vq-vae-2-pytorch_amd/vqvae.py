@@ -43,8 +43,10 @@ class _ConvBase(nn.Module):
         bound = 1 / math.sqrt(fan_in)
         nn.init.uniform_(self.bias, -bound, bound)
 
-    def nhwc(self, x, relu_in=False, relu_out=False, residual=None, out=None, grad_stash=None):
-        return ops.conv_op(x, self.weight, self.bias, self.spec, relu_in, relu_out, residual, out, grad_stash)
+    def nhwc(self, x, relu_in=False, relu_out=False, residual=None, out=None, grad_stash=None, mask_input=False,
+             premasked=False):
+        return ops.conv_op(x, self.weight, self.bias, self.spec, relu_in, relu_out, residual, out, grad_stash,
+                           mask_input, premasked)
 
     def forward(self, input):
         return ops.from_nhwc(self.nhwc(ops.to_nhwc(input)), self.spec.cout)
@@ -144,16 +146,17 @@ class ResBlock(nn.Module):
             Conv2d(channel, in_channel, 1),
         )
 
-    def nhwc(self, x, relu_in=False, relu_out=False, residual=None, out=None):
+    def nhwc(self, x, relu_in=False, relu_out=False, residual=None, out=None, premasked=False):
         assert not relu_in and residual is None
         c1, c2 = self.conv[1], self.conv[3]
-        return ops.ResBlockFn.apply(x, c1.weight, c1.bias, c2.weight, c2.bias, c1.spec, c2.spec, relu_out, out)
+        return ops.ResBlockFn.apply(x, c1.weight, c1.bias, c2.weight, c2.bias, c1.spec, c2.spec, relu_out, out,
+                                    premasked)
 
     def forward(self, input):
         return ops.from_nhwc(self.nhwc(ops.to_nhwc(input)), input.shape[1])
 
 
-def _run_blocks(blocks, x, out=None, grad_stash=None):
+def _run_blocks(blocks, x, out=None, grad_stash=None, mask_input=False, premasked=False):
     """Execute an nn.Sequential of {Conv2d, ConvTranspose2d, ReLU, ResBlock} with every ReLU fused
     into the conv that follows it (or, for a trailing ReLU, the op that precedes it)."""
     plan = []
@@ -182,12 +185,18 @@ def _run_blocks(blocks, x, out=None, grad_stash=None):
             x = ops.ReluFn.apply(x)
             if last and out is not None:
                 raise NotImplementedError("trailing stand-alone ReLU cannot target an output slice")
-        elif i == 0 and grad_stash is not None and isinstance(m, _ConvBase):
-            x = m.nhwc(x, relu_in=rin, relu_out=rout, out=out if last else None, grad_stash=grad_stash)
         else:
-            x = m.nhwc(x, relu_in=rin, relu_out=rout, out=out if last else None)
-    if grad_stash is not None and not (plan and isinstance(plan[0][0], _ConvBase)):
-        grad_stash.closed = True   # nobody will take it: the gradient has to flow the ordinary way
+            kw = {}
+            if i == 0 and isinstance(m, _ConvBase):
+                kw.update(grad_stash=grad_stash, mask_input=mask_input)
+            if last and rout and premasked:
+                kw["premasked"] = True
+            x = m.nhwc(x, relu_in=rin, relu_out=rout, out=out if last else None, **kw)
+    first_is_conv = bool(plan) and isinstance(plan[0][0], _ConvBase)
+    if (grad_stash is not None or mask_input) and not first_is_conv:
+        raise NotImplementedError("grad_stash / mask_input need a conv as the first block")
+    if premasked and not (plan and plan[-1][0] != "relu" and plan[-1][2]):
+        raise NotImplementedError("premasked needs a trailing ReLU fused into the last block")
     return x
 
 
@@ -216,8 +225,10 @@ class Encoder(nn.Module):
         self.blocks = nn.Sequential(*blocks)
         self.out_channels = channel
 
-    def nhwc(self, x, out=None, grad_stash=None):
-        return _run_blocks(self.blocks, x, out, grad_stash)
+    def nhwc(self, x, out=None, grad_stash=None, mask_input=False, premasked=False):
+        """grad_stash / mask_input / premasked: see ops.GradStash and ops.ConvFn -- the trailing ReLU's backward
+        mask and the fan-out gradient add are folded into the consumers' dgrad launches (training graph of VQVAE)."""
+        return _run_blocks(self.blocks, x, out, grad_stash, mask_input, premasked)
 
     def forward(self, input):
         return ops.from_nhwc(self.nhwc(ops.to_nhwc(input)), self.out_channels)
@@ -282,12 +293,15 @@ class VQVAE(nn.Module):
         if h % 8 or w % 8:
             raise RuntimeError("VQVAE: input height/width must be multiples of 8")
         cat = torch.empty((n, h // 4, w // 4, e + c), device=x.device, dtype=torch.float32)
-        enc_b = self.enc_b.nhwc(x, out=cat[..., e:])
         # enc_b feeds enc_t AND the concat (vqvae.py:225,233): the concat's gradient slice is added inside
-        # the dgrad launch of enc_t's first conv (ops.GradStash) instead of by an add kernel
-        skip = ops.GradStash() if torch.is_grad_enabled() else None
-        enc_t = self.enc_t.nhwc(enc_b, grad_stash=skip)
-        quant_t, diff_t, id_t = self.quantize_t(self.quantize_conv_t.nhwc(enc_t))
+        # the dgrad launch of enc_t's first conv (ops.GradStash) instead of by an add kernel, and that launch
+        # also applies the backward mask of enc_b's trailing ReLU (vqvae.py:122) to the sum; likewise
+        # quantize_conv_t's dgrad masks for enc_t's trailing ReLU -- no stand-alone ReLU-backward passes
+        fuse = torch.is_grad_enabled()
+        skip = ops.GradStash(strict=True) if fuse else None
+        enc_b = self.enc_b.nhwc(x, out=cat[..., e:], premasked=fuse)
+        enc_t = self.enc_t.nhwc(enc_b, grad_stash=skip, mask_input=fuse, premasked=fuse)
+        quant_t, diff_t, id_t = self.quantize_t(self.quantize_conv_t.nhwc(enc_t, mask_input=fuse))
         quant_t_for_dec, quant_t_ret = ops.FanOutFn.apply(quant_t)
         dec_t = self.dec_t.nhwc(quant_t_for_dec, out=cat[..., :e])
         enc_cat = ops.CatViewFn.apply(dec_t, enc_b, cat, skip)
