@@ -112,6 +112,16 @@ int vq2_resblock_fwd(int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cm, int
                      const float *w1p, const float *b1, const float *w2p, const float *b2, float *r, int32_t ldr,
                      float *y, int32_t ldy, vq2_stream_t stream);
 
+/* Fused ResBlock backward, data path (one launch instead of two dgrad launches):
+ *     dh = (r > 0) * dgrad_1x1(g)                    [N,H,W,Cm]  (output: both weight gradients read it)
+ *     dx = (x > 0) * dgrad_3x3(dh) + g               [N,H,W,C]
+ * g: gradient of the block output (already masked if the block had VQ2_RELU_OUT); r, x: saved by
+ * vq2_resblock_fwd; w2d / w1d: VQ2_PACK_DGRAD panels of the 1x1 and 3x3 weights.  Same (C, Cm) support
+ * as vq2_resblock_fwd. */
+int vq2_resblock_bwd_data(int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cm, const float *g, int32_t ldg,
+                          const float *r, int32_t ldr, const float *x, int32_t ldx, const float *w2d, const float *w1d,
+                          float *dh, int32_t lddh, float *dx, int32_t lddx, vq2_stream_t stream);
+
 /* dx = dgrad(dy) [* (mask > 0)] [+ residual]
  * wp: VQ2_PACK_DGRAD packing of w.  mask (shape of x, pixel stride ldmask): the
  * pre-ReLU input when the forward op had VQ2_RELU_IN (ReLU backward fused);

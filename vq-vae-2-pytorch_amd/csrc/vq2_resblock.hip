@@ -254,6 +254,254 @@ __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const ResFwdParams
         }
 }
 
+
+// ====================================================================== backward, data path
+//     dh = (r > 0) * conv1x1_dgrad(g)                 [N,H,W,32]   (saved: both weight gradients need it)
+//     dx = (x > 0) * conv3x3_dgrad(dh) + g            [N,H,W,128]
+// One launch per block instead of two.  Phase A recomputes dh on the tile's 10x18 halo patch (1.4x of a
+// GEMM that is 1/9 of the work) from 32-channel slices of g staged through LDS; the patch then stays in LDS
+// and phase B feeds all nine taps of the 3x3 data gradient from it by shifting the fragment base, streaming
+// only the weight panel of one tap at a time.  dh is never re-read from memory by this kernel.
+namespace rbb {
+using namespace rb;
+constexpr int SA = 32;                 // g channels per phase-A slice
+constexpr int LDA = SA + 4;
+constexpr int PROWS = 192;             // patch rows padded to 6 MFMA row blocks
+constexpr int GA_FLOATS = PROWS * LDA; // one g-patch slice buffer (also the size of the dh patch)
+constexpr int WA_FLOATS = CM * LDA;    // one slice of the 1x1 panel [32 cm][32 co]
+constexpr int WB_FLOATS = CC * LDA;    // one tap of the 3x3 panel [128 ci][32 cm]
+constexpr size_t LDS_BYTES = (size_t)(2 * GA_FLOATS + 2 * WA_FLOATS) * sizeof(float);   // 64,512
+static_assert(GA_FLOATS + 2 * WB_FLOATS <= 2 * GA_FLOATS + 2 * WA_FLOATS, "phase-B buffers alias the phase-A ones");
+}  // namespace rbb
+
+struct ResBwdParams {
+    const float *g;    // [N,H,W,ldg]  gradient of the block output
+    const float *r;    // [N,H,W,ldr]  saved relu(conv3x3) activation (mask of the inner ReLU)
+    const float *x;    // [N,H,W,ldx]  block input (mask of the outer ReLU)
+    const float *w2d;  // VQ2_PACK_DGRAD panel of the 1x1 weight: [32 cm][128 co]
+    const float *w1d;  // VQ2_PACK_DGRAD panel of the 3x3 weight: [128 ci][9 flipped taps][32 cm]
+    float *dh;         // [N,H,W,lddh]
+    float *dx;         // [N,H,W,lddx]
+    int N, H, W, ldg, ldr, ldx, lddh, lddx;
+    int tiles_x, tiles_y;
+};
+
+__global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdParams P) {
+    using namespace rbb;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Ga = smem;                          // [2][GA_FLOATS]   phase A: g patch slices
+    float *Wa = smem + 2 * GA_FLOATS;          // [2][WA_FLOATS]   phase A: 1x1 panel slices
+    float *Dh = smem;                          // phase B: dh patch [192][LDA]          (aliases Ga[0])
+    float *Wb = smem + GA_FLOATS;              // phase B: [2][WB_FLOATS] 3x3 tap panels (aliases Ga[1], Wa)
+
+    const int tid = threadIdx.x, lane = tid & 63, wq = tid >> 6;
+    const int l31 = lane & 31, fk = 4 * (lane >> 5), rowq = 4 * (lane >> 5);
+    const int tiles = P.tiles_x * P.tiles_y;
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int n = vid / tiles;
+    const int t = vid - n * tiles;
+    const int tyi = t / P.tiles_x;
+    const int y0 = tyi * TH, x0 = (t - tyi * P.tiles_x) * TW;
+    const int npix = P.N * P.H * P.W;
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.g), 0, npix * P.ldg * 4, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.r), 0, npix * P.ldr * 4, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x), 0, npix * P.ldx * 4, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rw2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.w2d), 0, CM * CC * 4, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rw1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.w1d), 0, CC * 9 * CM * 4, RSRC_FLAGS);
+
+    // pixel index of a patch row (or -1 outside the patch / the image)
+    auto patch_pix = [&](int pp) {
+        const int pr = pp / PW, pc = pp - pr * PW;
+        const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
+        return (pp < NPATCH && (unsigned)gy < (unsigned)P.H && (unsigned)gx < (unsigned)P.W) ? (n * P.H + gy) * P.W + gx : -1;
+    };
+
+    // ---------------------------------------------------------------- phase A: dh on the halo patch
+    constexpr int GA_LD = (NPATCH * (SA / 4) + 255) / 256;   // 6 float4 per thread per slice (1440 in all)
+    int ga_off[GA_LD];
+#pragma unroll
+    for (int j = 0; j < GA_LD; ++j) {
+        const int f = tid + 256 * j;
+        const int pix = patch_pix(f >> 3);
+        ga_off[j] = pix >= 0 ? pix * P.ldg * 4 + (f & 7) * 16 : OOB;
+    }
+    const int wa_off = ((tid >> 3) * CC) * 4 + (tid & 7) * 16;          // row cm = tid>>3 of the [32][128] panel
+    const int st8 = (tid >> 3) * LDA + (tid & 7) * 4;                   // LDS float offset of float4 number tid (+32 rows per j)
+    u32x4 rga[GA_LD], rwa;
+    auto issue_a = [&](int s) {
+        const int soff = s * SA * 4;
+#pragma unroll
+        for (int j = 0; j < GA_LD; ++j) rga[j] = __builtin_amdgcn_raw_buffer_load_b128(rg, ga_off[j], soff, 0);
+        rwa = __builtin_amdgcn_raw_buffer_load_b128(rw2, wa_off, soff, 0);
+    };
+    auto store_a = [&](int buf) {
+        float *a = Ga + buf * GA_FLOATS + st8;
+#pragma unroll
+        for (int j = 0; j < GA_LD; ++j)
+            if ((j + 1) * 256 <= NPATCH * (SA / 4) || tid + 256 * j < NPATCH * (SA / 4))
+                *reinterpret_cast<float4 *>(a + j * 32 * LDA) = u4_as_f4(rga[j]);
+        *reinterpret_cast<float4 *>(Wa + buf * WA_FLOATS + st8) = u4_as_f4(rwa);
+    };
+    // this wave's patch row blocks: wq, and wq + 4 for waves 0 and 1 (6 blocks of 32 rows cover the 180 patch rows)
+    const int nblk = wq < 2 ? 2 : 1;
+    int pixA[2];        // pixel of patch row 32*b + l31 (this lane's GEMM row), per block
+    float rmask[2][16];
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi) {
+        pixA[bi] = patch_pix(32 * (wq + 4 * bi) + l31);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int pix = __shfl(pixA[bi], rowq + (q & 3) + 8 * (q >> 2), 64);
+            rmask[bi][q] = (bi < nblk) ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                                             rr, pix >= 0 ? pix * P.ldr * 4 + l31 * 4 : OOB, 0, 0)) : 0.f;
+        }
+    }
+    f32x16 accA[2];
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) accA[bi][q] = 0.f;
+
+    // first tap panel of phase B: fetched behind the last phase-A slice
+    const int wb_goff = ((tid >> 3) * 9 * CM) * 4 + (tid & 7) * 16;     // row ci = tid>>3 (+32 per j), tap 0
+    u32x4 rwb[4];
+    auto issue_b = [&](int tap) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rwb[j] = __builtin_amdgcn_raw_buffer_load_b128(rw1, wb_goff + j * 32 * 9 * CM * 4, tap * CM * 4, 0);
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(Wb + buf * WB_FLOATS + st8 + j * 32 * LDA) = u4_as_f4(rwb[j]);
+    };
+
+    issue_a(0);
+    store_a(0);
+    __syncthreads();
+    constexpr int NSA = CC / SA;
+    for (int s = 0; s < NSA; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < NSA) issue_a(s + 1); else issue_b(0);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const float *b = Wa + buf * WA_FLOATS + l31 * LDA + fk;
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi) {
+                if (bi < nblk) {
+                    const float *a = Ga + buf * GA_FLOATS + (32 * (wq + 4 * bi) + l31) * LDA + fk;
+#pragma unroll
+                    for (int k8 = 0; k8 < SA / 8; ++k8) {
+                        const float4 fa = *reinterpret_cast<const float4 *>(a + 8 * k8);
+                        const float4 fb = *reinterpret_cast<const float4 *>(b + 8 * k8);
+                        accA[bi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, accA[bi], 0, 0, 0);
+                        accA[bi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, accA[bi], 0, 0, 0);
+                        accA[bi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, accA[bi], 0, 0, 0);
+                        accA[bi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, accA[bi], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < NSA) store_a(buf ^ 1);
+        __syncthreads();
+    }
+    // every wave is past its last phase-A fragment read: Dh and Wb may overwrite the slice buffers
+    {
+        const __amdgpu_buffer_rsrc_t rdh = __builtin_amdgcn_make_buffer_rsrc(P.dh, 0, npix * P.lddh * 4, RSRC_FLAGS);
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi) {
+            if (bi < nblk) {
+                // interior patch rows (the tile's own pixels) also go to memory for the weight-gradient kernels
+                const int pp = 32 * (wq + 4 * bi) + l31;
+                const int pr = pp / PW, pc = pp - pr * PW;
+                const int own = (pr >= 1 && pr <= TH && pc >= 1 && pc <= TW) ? pixA[bi] : -1;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int row = rowq + (q & 3) + 8 * (q >> 2);
+                    const float v = rmask[bi][q] > 0.f ? accA[bi][q] : 0.f;
+                    Dh[(32 * (wq + 4 * bi) + row) * LDA + l31] = v;
+                    const int pix = __shfl(own, row, 64);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rdh, pix >= 0 ? pix * P.lddh * 4 + l31 * 4 : OOB, 0, 0);
+                }
+            }
+        }
+    }
+    store_b(0);
+    __syncthreads();
+
+    // ---------------------------------------------------------------- phase B: 3x3 data gradient from the dh patch
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+    const int txr = l31 < 16 ? l31 : ((l31 + 14) & 15);      // rotated second row: conflict-free reads (see forward)
+    const int a_frag = ((2 * wq + (l31 >> 4)) * PW + txr) * LDA + fk;
+    // The epilogue operands are fetched BEHIND the MFMAs of phase B instead of in a burst after it (all resident
+    // workgroups reach their epilogue together: 200 MB of mask + skip + store traffic in lock-step otherwise):
+    // taps 0-3 fetch the outer-ReLU mask x of column block `tap` (folded to one bit per element a tap later),
+    // taps 5-8 fetch the skip gradient g of column block `tap - 5` into registers.
+    int pixr[16];
+    {
+        const int gy = y0 + 2 * wq + (l31 >> 4), gx = x0 + txr;
+        const int pix_lane = (gy < P.H && gx < P.W) ? (n * P.H + gy) * P.W + gx : -1;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) pixr[q] = __shfl(pix_lane, rowq + (q & 3) + 8 * (q >> 2), 64);
+    }
+    float mtmp[16], gres[4][16];
+    unsigned mbits[2] = {0u, 0u};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int buf = tap & 1;
+        if (tap + 1 < 9) issue_b(tap + 1);
+        if (tap < 4) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                mtmp[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                    rx, pixr[q] >= 0 ? pixr[q] * P.ldx * 4 + l31 * 4 + tap * 128 : OOB, 0, 0));
+        }
+        if (tap >= 5) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                gres[tap - 5][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                    rg, pixr[q] >= 0 ? pixr[q] * P.ldg * 4 + l31 * 4 + (tap - 5) * 128 : OOB, 0, 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const float *a = Dh + a_frag + ((tap / 3) * PW + (tap % 3)) * LDA;
+            const float *b = Wb + buf * WB_FLOATS + l31 * LDA + fk;
+#pragma unroll
+            for (int k8 = 0; k8 < CM / 8; ++k8) {
+                const float4 fa = *reinterpret_cast<const float4 *>(a + 8 * k8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 fb = *reinterpret_cast<const float4 *>(b + j * 32 * LDA + 8 * k8);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc[j], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap < 4) {   // the mask values have landed by now
+#pragma unroll
+            for (int q = 0; q < 16; ++q) mbits[tap >> 1] |= (mtmp[q] > 0.f ? 1u : 0u) << ((tap & 1) * 16 + q);
+        }
+        if (tap + 1 < 9) store_b(buf ^ 1);
+        __syncthreads();
+    }
+    // ---------------------------------------------------------------- epilogue: outer ReLU mask, skip gradient
+    const __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc(P.dx, 0, npix * P.lddx * 4, RSRC_FLAGS);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            float v = ((mbits[j >> 1] >> ((j & 1) * 16 + q)) & 1u) ? acc[j][q] : 0.f;
+            v += gres[j][q];
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rdx, pixr[q] >= 0 ? pixr[q] * P.lddx * 4 + l31 * 4 + j * 128 : OOB, 0, 0);
+        }
+}
+
 }  // namespace vq2
 
 extern "C" int vq2_resblock_supported(int32_t C, int32_t Cm) { return (C == vq2::rb::CC && Cm == vq2::rb::CM) ? 1 : 0; }
@@ -288,4 +536,37 @@ extern "C" int vq2_resblock_fwd(int32_t N, int32_t H, int32_t W, int32_t C, int3
     allow_big_lds(resblock_fwd_kernel, rb::LDS_BYTES);
     hipLaunchKernelGGL(resblock_fwd_kernel, dim3(grid), dim3(256), rb::LDS_BYTES, s, P);
     return check_launch("resblock_fwd_kernel");
+}
+
+extern "C" int vq2_resblock_bwd_data(int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cm, const float *g, int32_t ldg,
+                                     const float *r, int32_t ldr, const float *x, int32_t ldx, const float *w2d,
+                                     const float *w1d, float *dh, int32_t lddh, float *dx, int32_t lddx,
+                                     vq2_stream_t stream) {
+    using namespace vq2;
+    VQ2_REQUIRE(N > 0 && H > 0 && W > 0, "resblock_bwd_data: empty tensor");
+    if (!vq2_resblock_supported(C, Cm))
+        return set_error(VQ2_ERR_UNSUPPORTED, "resblock_bwd_data: fused kernel is built for channel=%d, n_res_channel=%d (got %d, %d)",
+                         rb::CC, rb::CM, C, Cm);
+    VQ2_REQUIRE(g && r && x && w2d && w1d && dh && dx, "resblock_bwd_data: null pointer");
+    VQ2_REQUIRE(aligned16(g) && aligned16(r) && aligned16(x) && aligned16(w2d) && aligned16(w1d) && aligned16(dh) && aligned16(dx),
+                "resblock_bwd_data: pointers must be 16-byte aligned");
+    VQ2_REQUIRE(ldg >= C && ldx >= C && lddx >= C && ldr >= Cm && lddh >= Cm && ldg % 4 == 0 && ldx % 4 == 0 &&
+                    lddx % 4 == 0 && ldr % 4 == 0 && lddh % 4 == 0,
+                "resblock_bwd_data: pixel strides must cover the channels and be multiples of 4");
+    const double npix = (double)N * H * W;
+    int ldmax = ldg > ldx ? ldg : ldx;
+    if (lddx > ldmax) ldmax = lddx;
+    VQ2_REQUIRE(npix * ldmax * 4.0 < (double)rb::OOB, "resblock_bwd_data: tensors must be smaller than %d bytes", rb::OOB);
+    ResBwdParams P{};
+    P.g = g; P.r = r; P.x = x; P.w2d = w2d; P.w1d = w1d; P.dh = dh; P.dx = dx;
+    P.N = N; P.H = H; P.W = W; P.ldg = ldg; P.ldr = ldr; P.ldx = ldx; P.lddh = lddh; P.lddx = lddx;
+    P.tiles_x = (W + rb::TW - 1) / rb::TW; P.tiles_y = (H + rb::TH - 1) / rb::TH;
+    const int grid = N * P.tiles_x * P.tiles_y;
+    hipStream_t s = to_stream(stream);
+    const char *name = "resblock_bwd_data";
+    if (prof_enabled()) name = prof_label("resblock_bwd_data|M=%d,C=%d,Cm=%d", N * H * W, C, Cm);
+    ProfScope prof(name, 2.0 * npix * (9.0 * C * Cm + (double)Cm * C), 4.0 * npix * (4.0 * C + 2.0 * Cm), s);
+    allow_big_lds(resblock_bwd_data_kernel, rbb::LDS_BYTES);
+    hipLaunchKernelGGL(resblock_bwd_data_kernel, dim3(grid), dim3(256), rbb::LDS_BYTES, s, P);
+    return check_launch("resblock_bwd_data_kernel");
 }

@@ -550,11 +550,20 @@ class ResBlockFn(Function):
         g = as_nhwc(dy)
         if ctx.relu_out and not ctx.premasked:
             g = relu_bwd(g, y)
-        # through conv1x1 and the inner ReLU (mask r > 0)
-        dh = conv_dgrad(s2, r.shape, g, w2, mask=r)
+        n, h, w, c = x.shape
+        if RESBLOCK_FUSED[0] and ctx.needs_input_grad[0] and lib.vq2_resblock_supported(c, s1.co) and s1.k == 3 and s2.k == 1:
+            # both data gradients in one launch (dh is recomputed on each tile's halo and kept in LDS)
+            dh = torch.empty((n, h, w, s1.co), device=x.device, dtype=torch.float32)
+            dx = torch.empty((n, h, w, c), device=x.device, dtype=torch.float32)
+            check(lib.vq2_resblock_bwd_data(n, h, w, c, s1.co, _p(g), ld_of(g), _p(r), ld_of(r), _p(x), ld_of(x),
+                                            _p(packed_weight(s2, w2, PACK_DGRAD)), _p(packed_weight(s1, w1, PACK_DGRAD)),
+                                            _p(dh), ld_of(dh), _p(dx), ld_of(dx), _stream()), "resblock_bwd_data")
+        else:
+            # through conv1x1 and the inner ReLU (mask r > 0)
+            dh = conv_dgrad(s2, r.shape, g, w2, mask=r)
+            # through conv3x3 and the outer ReLU (mask x > 0), plus the skip gradient
+            dx = conv_dgrad(s1, x.shape, dh, w1, mask=x, residual=g) if ctx.needs_input_grad[0] else None
         dw2, db2 = conv_wgrad(s2, r, g, False, w2, b2, ctx.needs_input_grad[3], ctx.needs_input_grad[4])
-        # through conv3x3 and the outer ReLU (mask x > 0), plus the skip gradient
-        dx = conv_dgrad(s1, x.shape, dh, w1, mask=x, residual=g) if ctx.needs_input_grad[0] else None
         dw1, db1 = conv_wgrad(s1, x, dh, True, w1, b1, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         return dx, dw1, db1, dw2, db2, None, None, None, None, None
 
