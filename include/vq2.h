@@ -233,6 +233,7 @@ int vq2_scale(const float *src, const float *scalar, float alpha, float *dst, in
  * 2*32*32*2 FLOP per MFMA.  Used by scripts/mfma_peak.py to measure the ceiling the chip sustains. */
 int vq2_debug_mfma_peak(float *scratch, int32_t blocks, int32_t iters, vq2_stream_t stream);
 /* diagnostic only: per-phase cycle stamps of the 128x128x32 conv tile into buf[16] (NULL = off) */
+int vq2_debug_set_rb_stamps(unsigned long long *buf); /* same for the fused ResBlock backward kernel: buf[64] */
 int vq2_debug_set_stamps(unsigned long long *buf);
 
 #ifdef __cplusplus

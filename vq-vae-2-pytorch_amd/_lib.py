@@ -73,6 +73,7 @@ def _load():
         "vq2_axpby": (C.c_int, [P, P, F, P, I64, P]),
         "vq2_scale": (C.c_int, [P, P, F, P, I64, P]),
         "vq2_debug_mfma_peak": (C.c_int, [P, I32, I32, P]),
+        "vq2_debug_set_rb_stamps": (C.c_int, [P]),
         "vq2_debug_set_stamps": (C.c_int, [P]),
     }
     for name, (res, args) in sig.items():

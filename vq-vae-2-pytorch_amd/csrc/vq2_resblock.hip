@@ -284,6 +284,7 @@ struct ResBwdParams {
     float *dx;         // [N,H,W,lddx]
     int N, H, W, ldg, ldr, ldx, lddh, lddx;
     int tiles_x, tiles_y;
+    unsigned long long *stamps;   // diagnostic (vq2_debug_set_stamps): s_memtime at the phase boundaries of 2 workgroups
 };
 
 __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdParams P) {
@@ -296,6 +297,11 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdP
 
     const int tid = threadIdx.x, lane = tid & 63, wq = tid >> 6;
     const int l31 = lane & 31, fk = 4 * (lane >> 5), rowq = 4 * (lane >> 5);
+    const int stamp_slot = (P.stamps && (blockIdx.x == 8 || blockIdx.x == 520)) ? (blockIdx.x == 8 ? 0 : 1) : -1;
+    auto stamp = [&](int i) {
+        if (stamp_slot >= 0 && lane == 0) P.stamps[(stamp_slot * 4 + wq) * 8 + i] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
     const int tiles = P.tiles_x * P.tiles_y;
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
     const int n = vid / tiles;
@@ -327,20 +333,25 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdP
     }
     const int wa_off = ((tid >> 3) * CC) * 4 + (tid & 7) * 16;          // row cm = tid>>3 of the [32][128] panel
     const int st8 = (tid >> 3) * LDA + (tid & 7) * 4;                   // LDS float offset of float4 number tid (+32 rows per j)
-    u32x4 rga[GA_LD], rwa;
+    // ALL slices of the g patch are requested up front (phase A has the registers to itself: 4 x 7 float4 per
+    // thread): one memory round trip for the whole phase instead of one per slice -- the 16-32 MFMAs a wave
+    // runs per slice are far too few to hide a fetch behind.
+    constexpr int NSA = CC / SA;
+    u32x4 rga[NSA][GA_LD], rwa[NSA];
     auto issue_a = [&](int s) {
         const int soff = s * SA * 4;
 #pragma unroll
-        for (int j = 0; j < GA_LD; ++j) rga[j] = __builtin_amdgcn_raw_buffer_load_b128(rg, ga_off[j], soff, 0);
-        rwa = __builtin_amdgcn_raw_buffer_load_b128(rw2, wa_off, soff, 0);
+        for (int j = 0; j < GA_LD; ++j) rga[s][j] = __builtin_amdgcn_raw_buffer_load_b128(rg, ga_off[j], soff, 0);
+        rwa[s] = __builtin_amdgcn_raw_buffer_load_b128(rw2, wa_off, soff, 0);
     };
-    auto store_a = [&](int buf) {
+    auto store_a = [&](int s) {
+        const int buf = s & 1;
         float *a = Ga + buf * GA_FLOATS + st8;
 #pragma unroll
         for (int j = 0; j < GA_LD; ++j)
             if ((j + 1) * 256 <= NPATCH * (SA / 4) || tid + 256 * j < NPATCH * (SA / 4))
-                *reinterpret_cast<float4 *>(a + j * 32 * LDA) = u4_as_f4(rga[j]);
-        *reinterpret_cast<float4 *>(Wa + buf * WA_FLOATS + st8) = u4_as_f4(rwa);
+                *reinterpret_cast<float4 *>(a + j * 32 * LDA) = u4_as_f4(rga[s][j]);
+        *reinterpret_cast<float4 *>(Wa + buf * WA_FLOATS + st8) = u4_as_f4(rwa[s]);
     };
     // this wave's patch row blocks: wq, and wq + 4 for waves 0 and 1 (6 blocks of 32 rows cover the 180 patch rows)
     const int nblk = wq < 2 ? 2 : 1;
@@ -374,13 +385,15 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdP
         for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(Wb + buf * WB_FLOATS + st8 + j * 32 * LDA) = u4_as_f4(rwb[j]);
     };
 
-    issue_a(0);
+#pragma unroll
+    for (int s = 0; s < NSA; ++s) issue_a(s);
     store_a(0);
     __syncthreads();
-    constexpr int NSA = CC / SA;
+    stamp(1);
+#pragma unroll
     for (int s = 0; s < NSA; ++s) {
         const int buf = s & 1;
-        if (s + 1 < NSA) issue_a(s + 1); else issue_b(0);
+        if (s + 1 == NSA) issue_b(0);
         __builtin_amdgcn_sched_barrier(0);
         {
             const float *b = Wa + buf * WA_FLOATS + l31 * LDA + fk;
@@ -401,9 +414,10 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdP
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < NSA) store_a(buf ^ 1);
+        if (s + 1 < NSA) store_a(s + 1);
         __syncthreads();
     }
+    stamp(2);
     // every wave is past its last phase-A fragment read: Dh and Wb may overwrite the slice buffers
     {
         const __amdgpu_buffer_rsrc_t rdh = __builtin_amdgcn_make_buffer_rsrc(P.dh, 0, npix * P.lddh * 4, RSRC_FLAGS);
@@ -427,6 +441,7 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdP
     }
     store_b(0);
     __syncthreads();
+    stamp(3);
 
     // ---------------------------------------------------------------- phase B: 3x3 data gradient from the dh patch
     f32x16 acc[4];
@@ -490,6 +505,7 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdP
         if (tap + 1 < 9) store_b(buf ^ 1);
         __syncthreads();
     }
+    stamp(4);
     // ---------------------------------------------------------------- epilogue: outer ReLU mask, skip gradient
     const __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc(P.dx, 0, npix * P.lddx * 4, RSRC_FLAGS);
 #pragma unroll
@@ -500,9 +516,14 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdP
             v += gres[j][q];
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rdx, pixr[q] >= 0 ? pixr[q] * P.lddx * 4 + l31 * 4 + j * 128 : OOB, 0, 0);
         }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(5);
 }
 
 }  // namespace vq2
+
+static unsigned long long *g_rb_stamps = nullptr;
+extern "C" int vq2_debug_set_rb_stamps(unsigned long long *buf) { g_rb_stamps = buf; return VQ2_OK; }
 
 extern "C" int vq2_resblock_supported(int32_t C, int32_t Cm) { return (C == vq2::rb::CC && Cm == vq2::rb::CM) ? 1 : 0; }
 
@@ -561,6 +582,7 @@ extern "C" int vq2_resblock_bwd_data(int32_t N, int32_t H, int32_t W, int32_t C,
     P.g = g; P.r = r; P.x = x; P.w2d = w2d; P.w1d = w1d; P.dh = dh; P.dx = dx;
     P.N = N; P.H = H; P.W = W; P.ldg = ldg; P.ldr = ldr; P.ldx = ldx; P.lddh = lddh; P.lddx = lddx;
     P.tiles_x = (W + rb::TW - 1) / rb::TW; P.tiles_y = (H + rb::TH - 1) / rb::TH;
+    P.stamps = g_rb_stamps;
     const int grid = N * P.tiles_x * P.tiles_y;
     hipStream_t s = to_stream(stream);
     const char *name = "resblock_bwd_data";

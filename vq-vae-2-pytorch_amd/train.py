@@ -2,6 +2,8 @@
 object: forward, MSE + 0.25*latent, backward, ONE packed all-reduce (gradients + the EMA sums of
 both quantizers) over RCCL, deferred EMA update, one-launch Adam, optional CycleScheduler.
 """
+import os
+
 import torch
 from torch import distributed as dist
 
@@ -44,7 +46,6 @@ class Stage1Trainer:
         self.world = dist_fn.get_world_size()
         self.optimizer.grad_scale = 1.0 / self.world  # DDP averages gradients (train_vqvae.py:166-171)
         self.comm_stream = torch.cuda.Stream() if self.world > 1 else None
-        import os
         # Overlap: when the gradients of the layers that back-propagate first (decoder side; they sit at the
         # TAIL of the arena) are complete, their slice is all-reduced on the side stream while the
         # encoder is still back-propagating; the head (encoder gradients + EMA statistics) follows.
