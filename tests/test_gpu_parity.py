@@ -147,6 +147,23 @@ def test_quantize_large_properties(amd):
     assert torch.equal(idx2, idx) and float(d2) < 1e-12
     # (4) diff equals the mean squared distance to the selected codes
     close(diff, (code - x).pow(2).mean(), rtol=1e-4)
+    # (5) a ragged row count on the 512-vector-workgroup path (M >= 131072, not a multiple of 128): indices,
+    #     loss and the complete EMA update against the oracle
+    xr = torch.cat([x.reshape(-1, D), x.reshape(-1, D)[:200] * 0.5], 0).contiguous()
+    q3 = amd.Quantize(D, K)
+    q3.load_state_dict({"embed": e, "cluster_size": torch.zeros(K), "embed_avg": e.clone()})
+    q3.to(dev()).train()
+    o3, d3, i3 = q3(xr)
+    emb, cs, ea = e.clone(), torch.zeros(K), e.clone()
+    ro, rd, ri = O.quantize_forward(xr.cpu(), emb, cs, ea, True)
+    badr = i3.cpu() != ri
+    mr, _ = O.quantize_margin(xr.cpu(), e)
+    assert int(badr.sum()) <= 8 and not bool((badr & (mr > 1e-3)).any())
+    close(d3, rd, rtol=1e-4)
+    if not bool(badr.any()):
+        close(q3.cluster_size, cs, rtol=1e-5, atol=1e-6)
+        close(q3.embed_avg, ea, rtol=1e-4, atol=1e-4)
+        close(q3.embed, emb, rtol=1e-3, atol=1e-4)
 
 
 def test_blocks(amd, golden):

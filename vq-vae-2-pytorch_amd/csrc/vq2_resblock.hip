@@ -582,8 +582,8 @@ extern "C" int vq2_resblock_bwd_data(int32_t N, int32_t H, int32_t W, int32_t C,
     P.g = g; P.r = r; P.x = x; P.w2d = w2d; P.w1d = w1d; P.dh = dh; P.dx = dx;
     P.N = N; P.H = H; P.W = W; P.ldg = ldg; P.ldr = ldr; P.ldx = ldx; P.lddh = lddh; P.lddx = lddx;
     P.tiles_x = (W + rb::TW - 1) / rb::TW; P.tiles_y = (H + rb::TH - 1) / rb::TH;
-    P.stamps = g_rb_stamps;
     const int grid = N * P.tiles_x * P.tiles_y;
+    P.stamps = g_rb_stamps;
     hipStream_t s = to_stream(stream);
     const char *name = "resblock_bwd_data";
     if (prof_enabled()) name = prof_label("resblock_bwd_data|M=%d,C=%d,Cm=%d", N * H * W, C, Cm);

@@ -16,11 +16,15 @@
 
 namespace vq2 {
 
-constexpr int VQ_CT = 128;      // codes staged per LDS tile
-constexpr int VQ_ROWS = 128;    // latent vectors per workgroup (32 per wave)
+constexpr int VQ_ROWS = 128;    // latent vectors per loss partial (32 per wave)
 
-template <int DP>  // DP = D rounded up to {16,32,64}
-__global__ __launch_bounds__(256) void vq_fwd_kernel(const float *__restrict__ x, int ldx,
+// DP = D rounded up to {16,32,64}; NW = waves per workgroup (32 vectors each); VQ_CT = codes staged per LDS tile.
+// <DP,4,128>: 128 vectors per workgroup, 32 KB tiles, ~5 workgroups per CU -- small launches.
+// <DP,16,512>: 512 vectors per workgroup and the reference's whole 512-code codebook (128 KB) staged ONCE, no
+// barrier in the main loop, 16 waves per CU; a quarter of the workgroups also means a quarter of the same-address
+// atomic bursts of the statistics when few codes are in use.  Chosen when the launch still fills every CU.
+template <int DP, int NW, int VQ_CT>
+__global__ __launch_bounds__(64 * NW) void vq_fwd_kernel(const float *__restrict__ x, int ldx,
                                                      const float *__restrict__ embed,   // [D][K]
                                                      const float *__restrict__ embedT,  // [K][D]
                                                      const float *__restrict__ enorm,   // [K]
@@ -29,14 +33,16 @@ __global__ __launch_bounds__(256) void vq_fwd_kernel(const float *__restrict__ x
                                                      float *__restrict__ loss_partial, float *__restrict__ counts,
                                                      float *__restrict__ sumsT) {
     constexpr int HS = DP / 2;  // MFMA k-steps; lane half h covers d in [h*HS, (h+1)*HS)
-    __shared__ __attribute__((aligned(16))) float Es[DP * VQ_CT];
-    __shared__ float En[VQ_CT];
-    __shared__ float wsum[4];
-    __shared__ int slead[VQ_ROWS];
+    constexpr int NT = 64 * NW, ROWS = 32 * NW;
+    extern __shared__ __attribute__((aligned(16))) float vq_smem[];
+    float *Es = vq_smem;                                   // [DP][VQ_CT]; later [ROWS slots][DP]
+    float *En = vq_smem + DP * VQ_CT;                      // [max(VQ_CT, ROWS)]; later slot codes
+    float *wsum = En + (VQ_CT > ROWS ? VQ_CT : ROWS);      // [NW]
+    int *slead = reinterpret_cast<int *>(wsum + NW);       // [ROWS]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, h = lane >> 5;
-    const int64_t row = (int64_t)blockIdx.x * VQ_ROWS + wave * 32 + col;
+    const int64_t row = (int64_t)blockIdx.x * ROWS + wave * 32 + col;
     const bool rv = row < M;
 
     // this lane's half of its latent vector, as MFMA B fragments
@@ -59,13 +65,14 @@ __global__ __launch_bounds__(256) void vq_fwd_kernel(const float *__restrict__ x
     for (int ct0 = 0; ct0 < K; ct0 += VQ_CT) {
         __syncthreads();
         // stage E[:, ct0:ct0+128] (zero-padded) and its norms
-        for (int t = tid; t < DP * (VQ_CT / 4); t += 256) {
+        for (int t = tid; t < DP * (VQ_CT / 4); t += NT) {
             const int d = t / (VQ_CT / 4), c4 = (t % (VQ_CT / 4)) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (d < D && ct0 + c4 < K) v = *reinterpret_cast<const float4 *>(embed + (size_t)d * K + ct0 + c4);
             *reinterpret_cast<float4 *>(Es + d * VQ_CT + c4) = v;
         }
-        if (tid < VQ_CT) En[tid] = (ct0 + tid < K) ? enorm[ct0 + tid] : 0.f;
+        // codes past K get norm +inf: their distance never wins, no per-element range test below
+        for (int t = tid; t < VQ_CT; t += NT) En[t] = (ct0 + t < K) ? enorm[ct0 + t] : __builtin_inff();
         __syncthreads();
 
 #pragma unroll 1
@@ -78,15 +85,26 @@ __global__ __launch_bounds__(256) void vq_fwd_kernel(const float *__restrict__ x
 #pragma unroll
             for (int s = 0; s < HS; ++s)
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ea[s * VQ_CT], xf[s], acc, 0, 0, 0);
+            // The argmin runs on the vector ALU, which the fp32 MFMAs of the other waves share: keep it to five
+            // instructions per distance.  fma(-2, dot, xx) rounds once and 2*dot is exact, so it equals the
+            // reference's (xx - 2*dot) bit for bit; the code index is (wave-uniform base + compile-time row) --
+            // this lane's constant 4*h is added once after the loop.
+            const int cbase = ct0 + sub * 32;          // scalar
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cl = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int c = ct0 + cl;
-                const float dist = (xx - 2.f * acc[r]) + En[cl];
-                if (c < K && dist < best) { best = dist; besti = c; }
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 en = *reinterpret_cast<const float4 *>(En + sub * 32 + 8 * r4 + 4 * h);
+                const float e4[4] = {en.x, en.y, en.z, en.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float dist = __builtin_fmaf(-2.f, acc[r4 * 4 + q], xx) + e4[q];
+                    const bool lt = dist < best;
+                    best = lt ? dist : best;
+                    besti = lt ? cbase + 8 * r4 + q : besti;
+                }
             }
         }
     }
+    besti += 4 * h;
     // combine the two half-waves (each saw half of the codes of every tile)
     {
         const float ob = __shfl_xor(best, 32, 64);
@@ -114,7 +132,8 @@ __global__ __launch_bounds__(256) void vq_fwd_kernel(const float *__restrict__ x
     lsum = wave_sum(lsum);
     if (lane == 0) wsum[wave] = lsum;
     __syncthreads();
-    if (tid == 0 && loss_partial) loss_partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    if (tid < NW / 4 && loss_partial && (int64_t)(blockIdx.x * (NW / 4) + tid) * VQ_ROWS < M)   // one partial per 128 vectors
+        loss_partial[blockIdx.x * (NW / 4) + tid] = (wsum[4 * tid] + wsum[4 * tid + 1]) + (wsum[4 * tid + 2] + wsum[4 * tid + 3]);
 
     // EMA statistics (vqvae.py:55-56): sumsT[code][:] += x rows.  Early in training (and on synthetic
     // data) most vectors pick the same few codes, and same-address float atomics serialise at the
@@ -123,9 +142,19 @@ __global__ __launch_bounds__(256) void vq_fwd_kernel(const float *__restrict__ x
     // code leaves the workgroup.
     if (sumsT) {
         __syncthreads();                                 // every wave is done with Es / En
-        float *ssum = Es;                                // [128 slots][DP]
-        int *scode = reinterpret_cast<int *>(En);        // [128] code of a slot, -1 = unused
-        const int64_t wrow0 = (int64_t)blockIdx.x * VQ_ROWS + wave * 32;
+        float *ssum = Es;                                // [ROWS slots][DP]
+        int *scode = reinterpret_cast<int *>(En);        // [ROWS] code of a slot, -1 = unused
+        // The wave's 32 vectors go from registers to its own 32 x DP corner of the (now free) staging buffer, so
+        // that the per-code sums below read rows with ~64-cycle LDS loads instead of dependent L2 round trips
+        // (16-byte groups XOR-swizzled by the row: conflict-free both ways).  Slot i later overwrites row i of
+        // the same corner: by then every row <= i has been consumed (leaders are taken in increasing order).
+        float *xt = Es + wave * 32 * DP;
+        constexpr int GM = DP / 4 - 1;
+#pragma unroll
+        for (int s = 0; s < HS; s += 4)
+            *reinterpret_cast<float4 *>(xt + col * DP + ((((h * HS + s) >> 2) ^ (col & GM)) << 2)) =
+                make_float4(xf[s], xf[s + 1], xf[s + 2], xf[s + 3]);
+        const int lg = lane >> 2, lq = lane & 3;         // this lane's 16-byte group / element when it reads column `lane`
         unsigned long long rem = __ballot(rv && h == 0);
         int nslots = 0;
         while (rem) {
@@ -137,7 +166,7 @@ __global__ __launch_bounds__(256) void vq_fwd_kernel(const float *__restrict__ x
             while (it) {
                 const int r = __ffsll((long long)it) - 1;
                 it &= it - 1;
-                if (lane < D) v += x[(wrow0 + r) * ldx + lane];
+                if (lane < DP) v += xt[r * DP + (((lg ^ (r & GM)) << 2) | lq)];
             }
             const int slot = wave * 32 + nslots;
             if (lane < D) ssum[slot * DP + lane] = v;
@@ -147,7 +176,7 @@ __global__ __launch_bounds__(256) void vq_fwd_kernel(const float *__restrict__ x
         }
         if (lane >= nslots && lane < 32) scode[wave * 32 + lane] = -1;
         __syncthreads();
-        if (tid < VQ_ROWS) {                             // leader of a code = its first slot in the workgroup
+        if (tid < ROWS) {                                // leader of a code = its first slot in the workgroup
             const int myc = scode[tid];
             int lead = tid;
             if (myc >= 0)
@@ -156,12 +185,12 @@ __global__ __launch_bounds__(256) void vq_fwd_kernel(const float *__restrict__ x
             slead[tid] = lead;
         }
         __syncthreads();
-        for (int sl = wave; sl < VQ_ROWS; sl += 4) {     // fold followers into their leader (LDS atomics)
+        for (int sl = wave; sl < ROWS; sl += NW) {       // fold followers into their leader (LDS atomics)
             const int l = slead[sl];
             if (scode[sl] >= 0 && l != sl && lane < D) atomicAdd(&ssum[l * DP + lane], ssum[sl * DP + lane]);
         }
         __syncthreads();
-        for (int sl = wave; sl < VQ_ROWS; sl += 4) {
+        for (int sl = wave; sl < ROWS; sl += NW) {
             const int c = scode[sl];
             if (c >= 0 && slead[sl] == sl && lane < D) atomicAdd(sumsT + (size_t)c * D + lane, ssum[sl * DP + lane]);
         }
@@ -321,15 +350,20 @@ extern "C" int vq2_vq_fwd(const float *x, int32_t ldx, const float *embed, const
     VQ2_REQUIRE(aligned16(x) && aligned16(embed) && aligned16(embedT) && (!out || aligned16(out)),
                 "vq_fwd: pointers must be 16-byte aligned");
     VQ2_REQUIRE((counts == nullptr) == (sumsT == nullptr), "vq_fwd: counts and sumsT go together");
-    const unsigned grid = (unsigned)((M + VQ_ROWS - 1) / VQ_ROWS);
     hipStream_t s = to_stream(stream);
     ProfScope prof("vq_fwd", 2.0 * (double)M * D * K, 4.0 * ((double)M * D * 2 + (double)D * K), s);
-#define VQ2_LAUNCH_VQ(DP)                                                                                         \
-    hipLaunchKernelGGL(vq_fwd_kernel<DP>, dim3(grid), dim3(256), 0, s, x, ldx, embed, embedT, enorm, M, D, K, idx, \
-                       out, ldo, loss_partial, counts, sumsT)
-    if (D <= 16) VQ2_LAUNCH_VQ(16);
-    else if (D <= 32) VQ2_LAUNCH_VQ(32);
-    else VQ2_LAUNCH_VQ(64);
+    const bool big = M >= 512 * 256;   // 512-vector workgroups still cover every CU
+#define VQ2_LAUNCH_VQ(DP, NW, CT)                                                                                    \
+    do {                                                                                                             \
+        const size_t lds = ((size_t)DP * CT + (CT > 32 * NW ? CT : 32 * NW) + NW + 32 * NW) * sizeof(float);         \
+        const unsigned grid = (unsigned)((M + 32 * NW - 1) / (32 * NW));                                             \
+        allow_big_lds(vq_fwd_kernel<DP, NW, CT>, lds);                                                               \
+        hipLaunchKernelGGL((vq_fwd_kernel<DP, NW, CT>), dim3(grid), dim3(64 * NW), lds, s, x, ldx, embed, embedT, enorm, M, \
+                           D, K, idx, out, ldo, loss_partial, counts, sumsT);                                        \
+    } while (0)
+    if (D <= 16) { if (big) VQ2_LAUNCH_VQ(16, 16, 512); else VQ2_LAUNCH_VQ(16, 4, 128); }
+    else if (D <= 32) { if (big) VQ2_LAUNCH_VQ(32, 16, 512); else VQ2_LAUNCH_VQ(32, 4, 128); }
+    else { if (big) VQ2_LAUNCH_VQ(64, 16, 512); else VQ2_LAUNCH_VQ(64, 4, 128); }
 #undef VQ2_LAUNCH_VQ
     if (int e = check_launch("vq_fwd_kernel")) return e;
     if (counts) {
