@@ -36,13 +36,22 @@ struct WgradParams {
 
 constexpr int WG_BKR = 32;  // reduction rows (pixels) per staged chunk
 
+// rows staged per pass by the 256 threads when a row has c4 float4: the largest power of two <= 256 / c4
+// (a 96-wide tile has 24 float4 per row -> 8 rows per pass, 64 threads sit the X staging out)
+constexpr int rows_per_pass(int c4) {
+    int r = 32;
+    while (r * c4 > 256) r >>= 1;
+    return r;
+}
+
 template <int WAVES_M, int WAVES_N, int MT, int NT>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
     constexpr int BMO = WAVES_M * MT * 32;  // tile rows  (o)
     constexpr int BNK = WAVES_N * NT * 32;  // tile cols  (k)
     constexpr int G_C4 = BMO / 4, X_C4 = BNK / 4;
-    constexpr int G_RSTEP = 256 / G_C4, X_RSTEP = 256 / X_C4;
+    constexpr int G_RSTEP = rows_per_pass(G_C4), X_RSTEP = rows_per_pass(X_C4);
     constexpr int G_LD = WG_BKR / G_RSTEP, X_LD = WG_BKR / X_RSTEP;
+    static_assert(G_C4 * G_RSTEP == 256, "every thread stages G");
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
     static_assert(G_C4 <= 256 && X_C4 <= 256 && G_LD >= 1 && X_LD >= 1, "tile/thread mapping");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -67,7 +76,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
     const int x_k = k0 + (tid % X_C4) * 4;
     const int x_r = tid / X_C4;
     const bool g_cv = g_c < P.O;
-    const bool x_kv = x_k < P.K;
+    const bool x_act = tid < X_C4 * X_RSTEP;       // threads beyond the last full staging row sit X out
+    const bool x_kv = x_act && x_k < P.K;
     int kh = 0, kw = 0, ci = 0;
     if (x_kv) {
         const int tap = x_k / P.I;
@@ -123,7 +133,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
             *reinterpret_cast<float4 *>(gs + (g_r + j * G_RSTEP) * BMO + (tid % G_C4) * 4) = P.relu_g ? relu4(rg[j]) : rg[j];
 #pragma unroll
         for (int j = 0; j < X_LD; ++j)
-            *reinterpret_cast<float4 *>(xs + (x_r + j * X_RSTEP) * BNK + (tid % X_C4) * 4) = P.relu_x ? relu4(rx[j]) : rx[j];
+            if (X_C4 * X_RSTEP == 256 || x_act)
+                *reinterpret_cast<float4 *>(xs + (x_r + j * X_RSTEP) * BNK + (tid % X_C4) * 4) = P.relu_x ? relu4(rx[j]) : rx[j];
     };
 
     f32x16 acc[MT][NT];
@@ -238,8 +249,9 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
     constexpr int BMO = WAVES_M * MT * 32;
     constexpr int BNK = WAVES_N * NT * 32;
     constexpr int G_C4 = BMO / 4, X_C4 = BNK / 4;
-    constexpr int G_RSTEP = 256 / G_C4, X_RSTEP = 256 / X_C4;
+    constexpr int G_RSTEP = rows_per_pass(G_C4), X_RSTEP = rows_per_pass(X_C4);
     constexpr int G_LD = WG_BKR / G_RSTEP, X_LD = WG_BKR / X_RSTEP;
+    static_assert(G_C4 * G_RSTEP == 256, "every thread stages G");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Gs = smem;
     float *Xs = smem + 2 * WG_BKR * BMO;
@@ -266,7 +278,8 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
     const int x_k = k0 + (tid % X_C4) * 4;
     const int x_r = tid / X_C4;
     const bool g_cv = g_c < P.O;
-    const bool x_kv = x_k < P.K;
+    const bool x_act = tid < X_C4 * X_RSTEP;       // threads beyond the last full staging row sit X out
+    const bool x_kv = x_act && x_k < P.K;
     int kh = 0, kw = 0, ci = 0;
     if (x_kv) {
         const int tap = x_k / P.I;
@@ -329,7 +342,8 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
 #pragma unroll
         for (int j = 0; j < X_LD; ++j) {
             const float4 v = as_f4w(rxv[j]);
-            *reinterpret_cast<float4 *>(xs + (x_r + j * X_RSTEP) * BNK + (tid % X_C4) * 4) = RELU_X ? relu4(v) : v;
+            if (X_C4 * X_RSTEP == 256 || x_act)
+                *reinterpret_cast<float4 *>(xs + (x_r + j * X_RSTEP) * BNK + (tid % X_C4) * 4) = RELU_X ? relu4(v) : v;
         }
     };
 
@@ -570,9 +584,13 @@ static WgradPlan plan_wgrad(const vq2_conv_desc *d) {
     }
     p.K = d->KH * d->KW * p.I;
     // output tile (o x k): the candidate that wastes the least padded work, larger tile on ties
-    static const int cand[5][2] = {{128, 128}, {64, 128}, {32, 256}, {128, 32}, {64, 64}};
+    // 128 x 96 = one kernel row of a 3x3 conv with 32 gathered channels (the ResBlock weight gradient with
+    // exchanged roles, K = 288): 48 MFMAs per wave and chunk instead of 16 for the same staging
+    static const int cand[6][2] = {{128, 128}, {64, 128}, {32, 256}, {128, 96}, {128, 32}, {64, 64}};
+    static const int t96 = getenv("VQ2_W96") ? atoi(getenv("VQ2_W96")) : 1;
     long best = -1;
-    for (int c = 0; c < 5; ++c) {
+    for (int c = 0; c < 6; ++c) {
+        if (cand[c][1] == 96 && (!t96 || p.M < 65536)) continue;   // measured: +6 % at 131072 rows, -9 % at 32768
         const long po = (p.O + cand[c][0] - 1) / cand[c][0] * cand[c][0];
         const long pk = (p.K + cand[c][1] - 1) / cand[c][1] * cand[c][1];
         const long work = po * pk;
@@ -764,6 +782,7 @@ static int wgrad_impl(const vq2_conv_desc *d, int flags, const float *x, const f
     if (p.bmo == 128 && p.bnk == 128) e = launch_wgrad<2, 2, 2, 2>(P, p.S, s);
     else if (p.bmo == 64 && p.bnk == 128) e = launch_wgrad<1, 4, 2, 1>(P, p.S, s);
     else if (p.bmo == 32) e = launch_wgrad<1, 4, 1, 2>(P, p.S, s);      // 32 x 256
+    else if (p.bmo == 128 && p.bnk == 96) e = launch_wgrad<4, 1, 1, 3>(P, p.S, s);
     else if (p.bmo == 128) e = launch_wgrad<4, 1, 1, 1>(P, p.S, s);     // 128 x 32 (1x1 convs with few inputs)
     else e = launch_wgrad<2, 2, 1, 1>(P, p.S, s);                       // 64 x 64
     if (e) return e;
