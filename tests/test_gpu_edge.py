@@ -36,6 +36,10 @@ RAGGED = [
     ("conv", 36, 132, 4, 2, 1, 1, 12, 8), ("conv", 5, 7, 3, 1, 1, 2, 4, 4), ("conv", 160, 136, 3, 1, 1, 1, 13, 11),
     ("convT", 8, 12, 4, 2, 1, 1, 3, 5), ("convT", 20, 3, 4, 2, 1, 2, 5, 3), ("convT", 16, 2, 4, 2, 1, 1, 4, 70),
     ("convT", 132, 68, 4, 2, 1, 1, 6, 7), ("convT", 5, 6, 4, 2, 1, 1, 2, 2),
+    # shapes that take the LDS-patch sub-pixel kernel (output channels % 64 == 0, reduction channels % 16 == 0):
+    # ragged tiles, two 64-channel groups, and the data gradient of a stride-2 conv
+    ("convT", 32, 64, 4, 2, 1, 2, 5, 19), ("convT", 16, 128, 4, 2, 1, 1, 9, 33), ("conv", 64, 48, 4, 2, 1, 2, 10, 14),
+    ("conv", 128, 32, 4, 2, 1, 1, 18, 34),
 ]
 
 

@@ -596,6 +596,216 @@ static int launch_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
     return check_launch("conv_gemm_kernel");
 }
 
+// ====================================================================== sub-pixel conv from an LDS patch
+// ConvTranspose2d(k4,s2,p1) forward and the data gradient of a k4,s2,p1 conv: four output phases, each a 2x2
+// stride-1 conv over the SAME 3x3 input neighbourhood.  As four independent GEMM launches-in-one (the kernel
+// above with phases = 4) every phase re-reads the input tensor (measured 640 MB of HBM fetch per launch for a
+// 67 MB input).  Here a workgroup owns an 8x16 tile of the INPUT grid and 64 output channels: the 10x18 halo
+// patch of a 16-channel slice is staged into LDS once and feeds all 16 (phase, tap) products by shifting the
+// fragment base; only the 2x2 weight panel of one phase is streamed per step (64 MFMAs per wave between
+// barriers, 4.75 staging loads instead of 8).  Accumulators: 4 phases x (32 px x 64 co) per wave = 128 VGPRs.
+namespace sp {
+constexpr int TH = 8, TW = 16, PW = TW + 2, NPATCH = (TH + 2) * PW;   // 180 patch pixels
+constexpr int CS = 16, LDK = CS + 4;
+constexpr int A_F4 = NPATCH * CS / 4;        // 720
+constexpr int A_FLOATS = NPATCH * LDK;       // 3600
+constexpr int B_ROWS = 4 * 64;               // (tap, co) rows of one phase panel
+constexpr int B_FLOATS = B_ROWS * LDK;       // 5120
+constexpr size_t LDS_BYTES = (size_t)2 * (A_FLOATS + B_FLOATS) * sizeof(float);   // 69,760: two workgroups per CU
+constexpr int SOOB = 0x7F000000;
+}  // namespace sp
+
+template <bool RELU_IN>
+__global__ __launch_bounds__(256, 2) void subpixel_conv_kernel(const ConvGemmParams P) {
+    using namespace sp;
+    constexpr int A_LD = (A_F4 + 255) / 256;   // 3
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                    // [2][A_FLOATS]
+    float *Bs = smem + 2 * A_FLOATS;     // [2][B_FLOATS]
+    const int tid = threadIdx.x, lane = tid & 63, wq = tid >> 6;
+    const int l31 = lane & 31, fk = 4 * (lane >> 5), rowq = 4 * (lane >> 5);
+    const int ncg = P.Co / 64;
+    const int tiles_x = (P.W + TW - 1) / TW, tiles_y = (P.H + TH - 1) / TH;
+    const int tiles = tiles_x * tiles_y;
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int cg = vid % ncg;
+    const int tv = vid / ncg;
+    const int n = tv / tiles;
+    const int t = tv - n * tiles;
+    const int tyi = t / tiles_x;
+    const int y0 = tyi * TH, x0 = (t - tyi * tiles_x) * TW;
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x), 0, P.N * P.H * P.W * P.ldx * 4, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.w), 0, 4 * P.Co * P.K * 4, RSRC_FLAGS);
+
+    int a_off[A_LD], b_off[4];
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+        const int f = tid + 256 * j;
+        a_off[j] = SOOB;
+        if (f < A_F4) {
+            const int pp = f >> 2;
+            const int pr = pp / PW, pc = pp - pr * PW;
+            const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
+            if ((unsigned)gy < (unsigned)P.H && (unsigned)gx < (unsigned)P.W)
+                a_off[j] = ((n * P.H + gy) * P.W + gx) * P.ldx * 4 + (f & 3) * 16;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (tid >> 2) + 64 * j;     // tap * 64 + co
+        b_off[j] = ((cg * 64 + (row & 63)) * P.K + (row >> 6) * P.Ci) * 4 + (tid & 3) * 16;
+    }
+    const int st_off = (tid >> 2) * LDK + (tid & 3) * 4;
+    const int phase_stride = P.Co * P.K * 4;     // bytes between the panels of two phases
+    u32x4 ra[A_LD], rb[4];
+    auto issue_a = [&](int s) {
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, a_off[j], s * CS * 4, 0);
+    };
+    auto issue_b = [&](int s, int ph) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_off[j], ph * phase_stride + s * CS * 4, 0);
+    };
+    auto store_a = [&](int buf) {
+        float *a = As + buf * A_FLOATS + st_off;
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j)
+            if ((j + 1) * 256 <= A_F4 || tid + 256 * j < A_F4) {
+                const float4 v = as_f4(ra[j]);
+                *reinterpret_cast<float4 *>(a + j * 64 * LDK) = RELU_IN ? relu4(v) : v;
+            }
+    };
+    auto store_b = [&](int buf) {
+        float *b = Bs + buf * B_FLOATS + st_off;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(b + j * 64 * LDK) = as_f4(rb[j]);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][j][r] = 0.f;
+
+    // GEMM row l31 of this wave = tile pixel (2*wq + l31/16, tx): second row rotated by 14 columns so that every
+    // tap's ds_read_b128 hits the LDS slots like 32 consecutive rows (see vq2_resblock.hip)
+    const int txr = l31 < 16 ? l31 : ((l31 + 14) & 15);
+    const int a_frag = ((2 * wq + (l31 >> 4)) * PW + txr) * LDK + fk;
+    const int b_frag = l31 * LDK + fk;
+    const int NS = P.Ci / CS;
+
+    issue_a(0);
+    issue_b(0, 0);
+    store_a(0);
+    store_b(0);
+    __syncthreads();
+    for (int s = 0; s < NS; ++s) {
+        const float *Ab = As + (s & 1) * A_FLOATS + a_frag;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const bool last = (s + 1 == NS) && p == 3;
+            if (!last) issue_b(p == 3 ? s + 1 : s, (p + 1) & 3);
+            if (p == 0 && s + 1 < NS) issue_a(s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const float *Bb = Bs + (p & 1) * B_FLOATS + b_frag;
+#pragma unroll
+                for (int tap = 0; tap < 4; ++tap) {
+                    const float *a = Ab + (((p >> 1) + (tap >> 1)) * PW + (p & 1) + (tap & 1)) * LDK;
+                    const float *b = Bb + tap * 64 * LDK;
+#pragma unroll
+                    for (int k8 = 0; k8 < CS / 8; ++k8) {
+                        const float4 fa = *reinterpret_cast<const float4 *>(a + 8 * k8);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const float4 fb = *reinterpret_cast<const float4 *>(b + j * 32 * LDK + 8 * k8);
+                            acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc[p][j], 0, 0, 0);
+                            acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc[p][j], 0, 0, 0);
+                            acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc[p][j], 0, 0, 0);
+                            acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc[p][j], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!last) store_b((p + 1) & 1);
+            if (p == 3 && s + 1 < NS) store_a((s + 1) & 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: output pixel (2*gy + ph, 2*gx + pw) of phase p = 2*ph + pw
+    const int ybytes = P.N * P.Hy * P.Wy * 4;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(P.y, 0, ybytes * P.ldy, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rmk =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.mask ? P.mask : P.y), 0, P.mask ? ybytes * P.ldm : 0, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.res ? P.res : P.y), 0, P.res ? ybytes * P.ldr : 0, RSRC_FLAGS);
+    const bool has_mask = P.mask != nullptr, has_res = P.res != nullptr;
+    const bool mask_first = has_mask && !P.mask_after, mask_last = has_mask && P.mask_after;
+    int pb_lane;   // output pixel of phase (0,0) for GEMM row l31, or -1
+    {
+        const int gy = y0 + 2 * wq + (l31 >> 4), gx = x0 + txr;
+        pb_lane = (gy < P.H && gx < P.W) ? (n * P.Hy + 2 * gy) * P.Wy + 2 * gx : -1;
+    }
+    const int ldy4 = P.ldy * 4, ldm4 = P.ldm * 4, ldr4 = P.ldr * 4;
+#pragma unroll
+    for (int rb8 = 0; rb8 < 16; rb8 += 8) {
+        int pb[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = rb8 + q;
+            pb[q] = __shfl(pb_lane, rowq + (r & 3) + 8 * (r >> 2), 64);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int poff = (p >> 1) * P.Wy + (p & 1);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int co = cg * 64 + j * 32 + l31;
+                const float bv = (P.bias && co < P.nbias) ? P.bias[co] : 0.f;
+                const int co4 = co * 4;
+                float mk[8], rs[8];
+                if (has_mask) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        mk[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rmk, pb[q] >= 0 ? (pb[q] + poff) * ldm4 + co4 : SOOB, 0, 0));
+                }
+                if (has_res) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        rs[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, pb[q] >= 0 ? (pb[q] + poff) * ldr4 + co4 : SOOB, 0, 0));
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float v = acc[p][j][rb8 + q] + bv;
+                    if (mask_first) v = (mk[q] > 0.f) ? v : 0.f;
+                    if (has_res) v += rs[q];
+                    if (mask_last) v = (mk[q] > 0.f) ? v : 0.f;
+                    if (P.relu_out) v = fmaxf(v, 0.f);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, pb[q] >= 0 ? (pb[q] + poff) * ldy4 + co4 : SOOB, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+static int launch_subpixel(const ConvGemmParams &P, hipStream_t s) {
+    const int tiles = ((P.W + sp::TW - 1) / sp::TW) * ((P.H + sp::TH - 1) / sp::TH);
+    dim3 grid(P.N * tiles * (P.Co / 64));
+    const char *name = "subpixel_conv";
+    if (prof_enabled()) name = prof_label("subpixel_conv|M=%d,N=%d,K=%d,ph4", P.M, P.Co, P.K);
+    ProfScope prof(name, P.flops, P.bytes, s);
+    auto kern = P.relu_in ? subpixel_conv_kernel<true> : subpixel_conv_kernel<false>;
+    allow_big_lds(kern, sp::LDS_BYTES);
+    hipLaunchKernelGGL(kern, grid, dim3(256), sp::LDS_BYTES, s, P);
+    return check_launch("subpixel_conv_kernel");
+}
+
 static unsigned long long *g_stamps = nullptr;  // set by vq2_debug_set_stamps: diagnostic cycle stamps
 
 static int tune(const char *name, int dflt) {
@@ -616,6 +826,15 @@ static int run_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
     const bool fast_ok = fast && P.KH * P.KW <= 32 && (long)P.N * P.H * P.W * P.ldx < lim &&
                          (long)P.N * P.Hy * P.Wy * P.ldy < lim && (long)P.N * P.Hy * P.Wy * (P.ldm > P.ldr ? P.ldm : P.ldr) < lim &&
                          (long)P.Co * P.K * P.phases < lim;
+    static const int subpix = tune("VQ2_SUBPIX", 1);
+    const long big = 0x7F000000L / 4;   // the patch kernel's out-of-range sentinel must stay above every tensor
+    // (a launch of <= 256 workgroups with a short depth is better off with the 64-row GEMM tiles: measured)
+    const long sp_wgs = (long)P.N * ((P.W + sp::TW - 1) / sp::TW) * ((P.H + sp::TH - 1) / sp::TH) * (P.Co / 64);
+    if (fast_ok && !g_stamps && subpix && P.phases == 4 && P.Co % 64 == 0 && P.Ci % 16 == 0 && P.K == 4 * P.Ci &&
+        (sp_wgs >= 512 || P.K >= 512) &&
+        (long)P.N * P.H * P.W * P.ldx < big && (long)P.N * P.Hy * P.Wy * P.ldy < big &&
+        (long)P.N * P.Hy * P.Wy * (P.ldm > P.ldr ? P.ldm : P.ldr) < big)
+        return launch_subpixel(P, s);
     if (fast_ok && !g_stamps) {
         static const int t32 = tune("VQ2_T32", 1), tk = tune("VQ2_TSHORTK", 0), t64 = tune("VQ2_T64", 0),
                          tsm = tune("VQ2_TSM", 1);
