@@ -2,7 +2,6 @@ cd $GRAFT_REPO_ROOT
 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
 B="python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-prof"
 $B > gpurun_out/ab1.json
-VQ2_SUBPIX=0 $B > gpurun_out/ab2.json
-$B > gpurun_out/ab3.json
-grep -o '"ms_per_step": [0-9.]*' gpurun_out/ab[1-3].json
+$B > gpurun_out/ab2.json
+grep -o '"ms_per_step": [0-9.]*' gpurun_out/ab[1-2].json
 python bench.py --steps 10 --warmup 5 --no-cpu-baseline --kernel-table gpurun_out/kt_k.json > /dev/null 2>&1

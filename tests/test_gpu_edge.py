@@ -40,6 +40,8 @@ RAGGED = [
     # ragged tiles, two 64-channel groups, and the data gradient of a stride-2 conv
     ("convT", 32, 64, 4, 2, 1, 2, 5, 19), ("convT", 16, 128, 4, 2, 1, 1, 9, 33), ("conv", 64, 48, 4, 2, 1, 2, 10, 14),
     ("conv", 128, 32, 4, 2, 1, 1, 18, 34),
+    # the <= 3-channel reconstruction kernel (32-channel slices): ragged 8x32 tiles
+    ("convT", 32, 3, 4, 2, 1, 2, 9, 35), ("convT", 64, 2, 4, 2, 1, 1, 17, 5),
 ]
 
 
