@@ -569,18 +569,19 @@ template <int WAVES_M, int WAVES_N, int MT, int NT, int BK, bool OCC4 = false>
 static int launch_conv_gemm_fast(const ConvGemmParams &P, hipStream_t s) {
     constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
     const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float) + (OCC4 ? 0 : 64 * sizeof(int));
+    const unsigned nwg = ((P.M + BM - 1) / BM) * ((P.Co + BN - 1) / BN) * P.phases;
     static const int pipe = tune("VQ2_PIPE", 1);
     auto kern = P.relu_in ? (pipe ? conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, true, true, OCC4>
                                   : conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, false, true, OCC4>)
                           : (pipe ? conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, true, false, OCC4>
                                   : conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, false, false, OCC4>);
     allow_big_lds(kern, lds);
-    dim3 grid(((P.M + BM - 1) / BM) * ((P.Co + BN - 1) / BN) * P.phases);
+    dim3 grid(nwg);
     const char *name = "conv_gemm";
     if (prof_enabled())
         name = prof_label("conv_gemm<%dx%dx%d>|M=%d,N=%d,K=%d,k%d,s%d,ph%d", BM, BN, BK, P.M, P.Co, P.K, P.KH, P.stride,
                           P.phases);
-    ProfScope prof(name, P.flops, P.bytes, s, BM == 128 && BN == 128 && BK == 32);
+    ProfScope prof(name, P.flops, P.bytes, s, BM == 128 && BN == 128);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, P);
     return check_launch("conv_gemm_fast_kernel");
 }
