@@ -982,6 +982,133 @@ __global__ __launch_bounds__(256) void convT_small_kernel(const float *__restric
     }
 }
 
+// Matrix-core form of the same layer: v_mfma_f32_4x4x1_16B_f32 computes 16 independent 4x4 outer products per
+// instruction at the full fp32 rate, and "4 columns" is exactly the padded channel count of the reconstruction.
+// Block b of a wave = 4 consecutive input positions (rows of the 4x4), columns = the 4 output channels; a lane
+// (4b + i) feeds its own position's activations as A and the weight of channel (lane & 3) as B, one input
+// channel per instruction; the four output phases keep one 4-VGPR accumulator each.  The 10x34 halo patch of a
+// 16-channel slice and the 16 x 4 weight rows of that slice are staged in LDS; every (neighbour, channel quad)
+// is read once and used by up to four phases.
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+namespace ctm {
+constexpr int TH = 8, TW = 32, PW = TW + 2, NP = (TH + 2) * PW;   // 340 patch pixels
+constexpr int CS = 16, LD = CS + 4;
+constexpr int X_FLOATS = NP * LD, W_FLOATS = 64 * LD;
+constexpr size_t LDS_BYTES = (size_t)2 * (X_FLOATS + W_FLOATS) * sizeof(float);   // 64,640
+constexpr int COOB = 0x7F000000;
+}  // namespace ctm
+
+__global__ __launch_bounds__(256, 2) void convT_small_mfma_kernel(const float *__restrict__ x, int ldx,
+                                                                  const float *__restrict__ wk,   // [16 taps][4 co][Ci]
+                                                                  const float *__restrict__ bias, int nbias,
+                                                                  float *__restrict__ y, int ldy, int N, int H, int W, int Ci,
+                                                                  int relu_in) {
+    using namespace ctm;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Xs = smem;                     // [2][X_FLOATS]
+    float *Ws = smem + 2 * X_FLOATS;      // [2][W_FLOATS]
+    const int tid = threadIdx.x, lane = tid & 63, wq = tid >> 6;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int n = vid / (tiles_x * tiles_y);
+    const int tt = vid - n * tiles_x * tiles_y;
+    const int i0 = (tt / tiles_x) * TH, j0 = (tt % tiles_x) * TW;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, N * H * W * ldx * 4, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wk), 0, 64 * Ci * 4, RSRC_FLAGS);
+
+    constexpr int X_LD = (NP * (CS / 4) + 255) / 256;   // 6
+    int x_off[X_LD];
+#pragma unroll
+    for (int j = 0; j < X_LD; ++j) {
+        const int f = tid + 256 * j;
+        x_off[j] = COOB;
+        if (f < NP * (CS / 4)) {
+            const int pp = f >> 2;
+            const int gi = i0 - 1 + pp / PW, gj = j0 - 1 + pp % PW;
+            if ((unsigned)gi < (unsigned)H && (unsigned)gj < (unsigned)W) x_off[j] = ((n * H + gi) * W + gj) * ldx * 4 + (f & 3) * 16;
+        }
+    }
+    const int w_off = (tid >> 2) * Ci * 4 + (tid & 3) * 16;     // row (tap, co) = tid >> 2
+    const int st_off = (tid >> 2) * LD + (tid & 3) * 4;
+    u32x4 rxv[X_LD], rwv;
+    auto issue = [&](int s) {
+#pragma unroll
+        for (int j = 0; j < X_LD; ++j) rxv[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, x_off[j], s * CS * 4, 0);
+        rwv = __builtin_amdgcn_raw_buffer_load_b128(rw, w_off, s * CS * 4, 0);
+    };
+    auto store = [&](int buf) {
+        float *xs = Xs + buf * X_FLOATS + st_off;
+#pragma unroll
+        for (int j = 0; j < X_LD; ++j)
+            if ((j + 1) * 256 <= NP * (CS / 4) || tid + 256 * j < NP * (CS / 4)) {
+                const float4 v = as_f4(rxv[j]);
+                *reinterpret_cast<float4 *>(xs + j * 64 * LD) = relu_in ? relu4(v) : v;
+            }
+        *reinterpret_cast<float4 *>(Ws + buf * W_FLOATS + st_off) = as_f4(rwv);
+    };
+
+    f32x4m acc[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) acc[p] = f32x4m{0.f, 0.f, 0.f, 0.f};
+    // this lane's input position: row 2*wq + lane/32, column lane%32 of the tile
+    const int a_base = ((2 * wq + (lane >> 5)) * PW + (lane & 31)) * LD;
+    const int b_base = (lane & 3) * LD;
+    const int NS = Ci / CS;
+    issue(0);
+    store(0);
+    __syncthreads();
+    for (int s = 0; s < NS; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < NS) issue(s + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const float *xs = Xs + buf * X_FLOATS + a_base;
+        const float *ws = Ws + buf * W_FLOATS + b_base;
+#pragma unroll
+        for (int kq = 0; kq < CS / 4; ++kq) {
+            float4 av[9];
+#pragma unroll
+            for (int nb = 0; nb < 9; ++nb) av[nb] = *reinterpret_cast<const float4 *>(xs + ((nb / 3) * PW + nb % 3) * LD + kq * 4);
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+                for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            // output phase (ph, pw) reads neighbour (ph + a, pw + b) through kernel tap (3-2a-ph, 3-2b-pw)
+                            const int tap = (3 - 2 * a - ph) * 4 + (3 - 2 * b - pw);
+                            const float4 bv = *reinterpret_cast<const float4 *>(ws + tap * 4 * LD + kq * 4);
+                            const float4 xv = av[(ph + a) * 3 + pw + b];
+                            f32x4m c = acc[ph * 2 + pw];
+                            c = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.x, bv.x, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.y, bv.y, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.z, bv.z, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.w, bv.w, c, 0, 0, 0);
+                            acc[ph * 2 + pw] = c;
+                        }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < NS) store(buf ^ 1);
+        __syncthreads();
+    }
+    // accumulator VGPR r of lane (4b + j) = position 4b + r of the wave, channel j
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y, 0, N * 4 * H * W * ldy * 4, RSRC_FLAGS);
+    const int co = lane & 3;
+    const float bvs = (bias && co < nbias) ? bias[co] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int pos = (lane & ~3) + r;
+        const int gi = i0 + 2 * wq + (pos >> 5), gj = j0 + (pos & 31);
+        const bool ok = gi < H && gj < W;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int pix = (n * 2 * H + 2 * gi + (p >> 1)) * (2 * W) + 2 * gj + (p & 1);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[p][r] + bvs), ry, ok ? (pix * ldy + co) * 4 : COOB, 0, 0);
+        }
+    }
+}
+
 static bool use_convT_small(const vq2_conv_desc *d) {
     return d->transposed && d->Co == 4 && d->Cor >= 1 && d->Cor <= 3 && d->Ci % 16 == 0 && d->N <= 65535;
 }
@@ -1118,6 +1245,14 @@ extern "C" int vq2_conv_fwd(const vq2_conv_desc *d, int flags, const float *x, c
         if (prof_enabled()) name = prof_label("convT_small|N=%d,H=%d,W=%d,Ci=%d", d->N, d->H, d->W, d->Ci);
         ProfScope prof(name, 2.0 * d->N * d->H * d->W * 16.0 * d->Ci * cor,
                        4.0 * ((double)d->N * d->H * d->W * d->Ci + 4.0 * d->N * d->H * d->W * cor), s);
+        static const int ct_mfma = tune("VQ2_CT_MFMA", 1);
+        if (ct_mfma && (double)d->N * 4 * d->H * d->W * d->ldy * 4 < (double)ctm::COOB && (double)d->N * d->H * d->W * d->ldx * 4 < (double)ctm::COOB) {
+            const int g = ((d->W + ctm::TW - 1) / ctm::TW) * ((d->H + ctm::TH - 1) / ctm::TH) * d->N;
+            allow_big_lds(convT_small_mfma_kernel, ctm::LDS_BYTES);
+            hipLaunchKernelGGL(convT_small_mfma_kernel, dim3(g), dim3(256), ctm::LDS_BYTES, s, x, d->ldx, wp, bias, cor, y,
+                               d->ldy, d->N, d->H, d->W, d->Ci, (flags & VQ2_RELU_IN) != 0);
+            return check_launch("convT_small_mfma_kernel");
+        }
         dim3 grid((d->W + T3_TW - 1) / T3_TW, (d->H + T3_TH - 1) / T3_TH, d->N);
         hipLaunchKernelGGL(convT_small_kernel, grid, dim3(256), 0, s, x, d->ldx, wp, bias, cor, y, d->ldy, d->H, d->W, d->Ci,
                            (flags & VQ2_RELU_IN) != 0);
