@@ -991,13 +991,15 @@ __global__ __launch_bounds__(256) void convT_small_kernel(const float *__restric
 // is read once and used by up to four phases.
 typedef float f32x4m __attribute__((ext_vector_type(4)));
 namespace ctm {
-constexpr int TH = 8, TW = 32, PW = TW + 2, NP = (TH + 2) * PW;   // 340 patch pixels
-constexpr int CS = 16, LD = CS + 4;
+constexpr int TH = 16, TW = 32, PW = TW + 2, NP = (TH + 2) * PW;   // 612 patch pixels
+constexpr int CS = 8, LD = CS + 4;          // 48-byte LDS rows: conflict-free ds_read_b128 for consecutive pixels
 constexpr int X_FLOATS = NP * LD, W_FLOATS = 64 * LD;
-constexpr size_t LDS_BYTES = (size_t)2 * (X_FLOATS + W_FLOATS) * sizeof(float);   // 64,640
+constexpr size_t LDS_BYTES = (size_t)2 * (X_FLOATS + W_FLOATS) * sizeof(float);   // 64,896: two workgroups per CU
 constexpr int COOB = 0x7F000000;
 }  // namespace ctm
 
+// Each wave owns TWO sets of 64 input positions (rows 4*wq + 2u + lane/32): a weight fragment read from LDS is
+// used by both, which halves the broadcast reads that otherwise saturate the LDS pipe before the matrix pipe.
 __global__ __launch_bounds__(256, 2) void convT_small_mfma_kernel(const float *__restrict__ x, int ldx,
                                                                   const float *__restrict__ wk,   // [16 taps][4 co][Ci]
                                                                   const float *__restrict__ bias, int nbias,
@@ -1016,20 +1018,23 @@ __global__ __launch_bounds__(256, 2) void convT_small_mfma_kernel(const float *_
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, N * H * W * ldx * 4, RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wk), 0, 64 * Ci * 4, RSRC_FLAGS);
 
-    constexpr int X_LD = (NP * (CS / 4) + 255) / 256;   // 6
+    constexpr int QPR = CS / 4;                          // float4 per staged row
+    constexpr int X_F4 = NP * QPR;                       // 1224
+    constexpr int X_LD = (X_F4 + 255) / 256;             // 5
     int x_off[X_LD];
 #pragma unroll
     for (int j = 0; j < X_LD; ++j) {
         const int f = tid + 256 * j;
         x_off[j] = COOB;
-        if (f < NP * (CS / 4)) {
-            const int pp = f >> 2;
+        if (f < X_F4) {
+            const int pp = f / QPR;
             const int gi = i0 - 1 + pp / PW, gj = j0 - 1 + pp % PW;
-            if ((unsigned)gi < (unsigned)H && (unsigned)gj < (unsigned)W) x_off[j] = ((n * H + gi) * W + gj) * ldx * 4 + (f & 3) * 16;
+            if ((unsigned)gi < (unsigned)H && (unsigned)gj < (unsigned)W) x_off[j] = ((n * H + gi) * W + gj) * ldx * 4 + (f % QPR) * 16;
         }
     }
-    const int w_off = (tid >> 2) * Ci * 4 + (tid & 3) * 16;     // row (tap, co) = tid >> 2
-    const int st_off = (tid >> 2) * LD + (tid & 3) * 4;
+    const bool w_act = tid < 64 * QPR;
+    const int w_off = w_act ? (tid / QPR) * Ci * 4 + (tid % QPR) * 16 : COOB;     // row (tap, co) = tid / QPR
+    const int st_off = (tid / QPR) * LD + (tid % QPR) * 4;
     u32x4 rxv[X_LD], rwv;
     auto issue = [&](int s) {
 #pragma unroll
@@ -1040,18 +1045,19 @@ __global__ __launch_bounds__(256, 2) void convT_small_mfma_kernel(const float *_
         float *xs = Xs + buf * X_FLOATS + st_off;
 #pragma unroll
         for (int j = 0; j < X_LD; ++j)
-            if ((j + 1) * 256 <= NP * (CS / 4) || tid + 256 * j < NP * (CS / 4)) {
+            if ((j + 1) * 256 <= X_F4 || tid + 256 * j < X_F4) {
                 const float4 v = as_f4(rxv[j]);
-                *reinterpret_cast<float4 *>(xs + j * 64 * LD) = relu_in ? relu4(v) : v;
+                *reinterpret_cast<float4 *>(xs + j * (256 / QPR) * LD) = relu_in ? relu4(v) : v;
             }
-        *reinterpret_cast<float4 *>(Ws + buf * W_FLOATS + st_off) = as_f4(rwv);
+        if (w_act) *reinterpret_cast<float4 *>(Ws + buf * W_FLOATS + st_off) = as_f4(rwv);
     };
 
-    f32x4m acc[4];
+    f32x4m acc[2][4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) acc[p] = f32x4m{0.f, 0.f, 0.f, 0.f};
-    // this lane's input position: row 2*wq + lane/32, column lane%32 of the tile
-    const int a_base = ((2 * wq + (lane >> 5)) * PW + (lane & 31)) * LD;
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[u][p] = f32x4m{0.f, 0.f, 0.f, 0.f};
+    const int a_base = ((4 * wq + (lane >> 5)) * PW + (lane & 31)) * LD;   // set u adds 2 patch rows
     const int b_base = (lane & 3) * LD;
     const int NS = Ci / CS;
     issue(0);
@@ -1064,10 +1070,13 @@ __global__ __launch_bounds__(256, 2) void convT_small_mfma_kernel(const float *_
         const float *xs = Xs + buf * X_FLOATS + a_base;
         const float *ws = Ws + buf * W_FLOATS + b_base;
 #pragma unroll
-        for (int kq = 0; kq < CS / 4; ++kq) {
-            float4 av[9];
+        for (int kq = 0; kq < QPR; ++kq) {
+            float4 av[2][9];
 #pragma unroll
-            for (int nb = 0; nb < 9; ++nb) av[nb] = *reinterpret_cast<const float4 *>(xs + ((nb / 3) * PW + nb % 3) * LD + kq * 4);
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int nb = 0; nb < 9; ++nb)
+                    av[u][nb] = *reinterpret_cast<const float4 *>(xs + ((2 * u + nb / 3) * PW + nb % 3) * LD + kq * 4);
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
@@ -1079,34 +1088,39 @@ __global__ __launch_bounds__(256, 2) void convT_small_mfma_kernel(const float *_
                             // output phase (ph, pw) reads neighbour (ph + a, pw + b) through kernel tap (3-2a-ph, 3-2b-pw)
                             const int tap = (3 - 2 * a - ph) * 4 + (3 - 2 * b - pw);
                             const float4 bv = *reinterpret_cast<const float4 *>(ws + tap * 4 * LD + kq * 4);
-                            const float4 xv = av[(ph + a) * 3 + pw + b];
-                            f32x4m c = acc[ph * 2 + pw];
-                            c = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.x, bv.x, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.y, bv.y, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.z, bv.z, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.w, bv.w, c, 0, 0, 0);
-                            acc[ph * 2 + pw] = c;
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                const float4 xv = av[u][(ph + a) * 3 + pw + b];
+                                f32x4m c = acc[u][ph * 2 + pw];
+                                c = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.x, bv.x, c, 0, 0, 0);
+                                c = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.y, bv.y, c, 0, 0, 0);
+                                c = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.z, bv.z, c, 0, 0, 0);
+                                c = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.w, bv.w, c, 0, 0, 0);
+                                acc[u][ph * 2 + pw] = c;
+                            }
                         }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (s + 1 < NS) store(buf ^ 1);
         __syncthreads();
     }
-    // accumulator VGPR r of lane (4b + j) = position 4b + r of the wave, channel j
+    // accumulator VGPR r of lane (4b + j) = position 4b + r of the wave's set, channel j
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y, 0, N * 4 * H * W * ldy * 4, RSRC_FLAGS);
     const int co = lane & 3;
     const float bvs = (bias && co < nbias) ? bias[co] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int pos = (lane & ~3) + r;
-        const int gi = i0 + 2 * wq + (pos >> 5), gj = j0 + (pos & 31);
-        const bool ok = gi < H && gj < W;
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int pix = (n * 2 * H + 2 * gi + (p >> 1)) * (2 * W) + 2 * gj + (p & 1);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[p][r] + bvs), ry, ok ? (pix * ldy + co) * 4 : COOB, 0, 0);
+        for (int r = 0; r < 4; ++r) {
+            const int pos = (lane & ~3) + r;
+            const int gi = i0 + 4 * wq + 2 * u + (pos >> 5), gj = j0 + (pos & 31);
+            const bool ok = gi < H && gj < W;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int pix = (n * 2 * H + 2 * gi + (p >> 1)) * (2 * W) + 2 * gj + (p & 1);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[u][p][r] + bvs), ry, ok ? (pix * ldy + co) * 4 : COOB, 0, 0);
+            }
         }
-    }
 }
 
 static bool use_convT_small(const vq2_conv_desc *d) {
