@@ -117,10 +117,15 @@ int vq2_resblock_fwd(int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cm, int
  *     dx = (x > 0) * dgrad_3x3(dh) + g               [N,H,W,C]
  * g: gradient of the block output (already masked if the block had VQ2_RELU_OUT); r, x: saved by
  * vq2_resblock_fwd; w2d / w1d: VQ2_PACK_DGRAD panels of the 1x1 and 3x3 weights.  Same (C, Cm) support
- * as vq2_resblock_fwd. */
+ * as vq2_resblock_fwd. *
+ * w2_ws (optional, vq2_resblock_w2_workspace_bytes): the kernel also leaves, per workgroup, the partial 1x1
+ * weight and bias gradients of its own pixels there (it holds g and r anyway), which saves the separate
+ * vq2_conv_wgrad launch of the 1x1 conv: fill a vq2_wgrad_job with vq2_resblock_w2_job_init and hand it to
+ * vq2_wgrad_reduce_batched together with the other layers' jobs. */
+size_t vq2_resblock_w2_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cm);
 int vq2_resblock_bwd_data(int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cm, const float *g, int32_t ldg,
                           const float *r, int32_t ldr, const float *x, int32_t ldx, const float *w2d, const float *w1d,
-                          float *dh, int32_t lddh, float *dx, int32_t lddx, vq2_stream_t stream);
+                          float *dh, int32_t lddh, float *dx, int32_t lddx, void *w2_ws, vq2_stream_t stream);
 
 /* dx = dgrad(dy) [* (mask > 0)] [+ residual]
  * wp: VQ2_PACK_DGRAD packing of w.  mask (shape of x, pixel stride ldmask): the
@@ -164,6 +169,9 @@ int vq2_conv_wgrad_partial(const vq2_conv_desc *d, int flags, const float *x, co
                            size_t ws_bytes, vq2_stream_t stream);
 int vq2_wgrad_job_init(const vq2_conv_desc *d, const void *ws, float *dw, float *db, vq2_wgrad_job *job);
 int vq2_wgrad_reduce_batched(const vq2_wgrad_job *jobs_dev, int32_t njobs, int64_t total_units, vq2_stream_t stream);
+/* job of the 1x1 weight gradient that vq2_resblock_bwd_data left in `ws` (see there) */
+int vq2_resblock_w2_job_init(int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cm, const void *ws, float *dw, float *db,
+                             vq2_wgrad_job *job);
 
 /* out[c] = sum over rows of x[.,c] (stand-alone column sums).  ws: >= vq2_colsum_workspace_bytes. */
 size_t vq2_colsum_workspace_bytes(int64_t rows, int32_t C);

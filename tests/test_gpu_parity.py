@@ -422,6 +422,11 @@ def _step_vs_oracle(amd, cfg, size, batch, seed):
     for k, p in m.named_parameters():
         if p.grad is not None:
             close(p.grad.norm(), ref["grads"][k].norm(), rtol=2e-3 if exact else 2e-2, what=k)
+            # element-wise for the ResBlock convs (their gradients come out of the fused backward kernel and its
+            # per-workgroup 1x1 slabs) and the first / last layers
+            if exact and (".conv." in k or k.startswith("enc_b.blocks.0") or k.startswith("dec.blocks.6")):
+                gref = ref["grads"][k]
+                close(p.grad, gref, rtol=2e-3, atol=2e-4 * float(gref.abs().max()) + 1e-9, what=k + " (element-wise)")
     sd = m.state_dict()
     for k in ("quantize_t.cluster_size", "quantize_b.cluster_size", "quantize_b.embed_avg", "enc_b.blocks.0.weight",
               "dec.blocks.6.bias"):

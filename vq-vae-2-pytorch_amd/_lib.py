@@ -57,7 +57,9 @@ def _load():
         "vq2_nhwc_to_nchw": (C.c_int, [P, P, I32, I32, I32, I32, I32, P]),
         "vq2_relu_bwd": (C.c_int, [P, I32, P, I32, P, I32, I64, I32, P]),
         "vq2_resblock_supported": (C.c_int, [I32, I32]),
-        "vq2_resblock_bwd_data": (C.c_int, [I32, I32, I32, I32, I32, P, I32, P, I32, P, I32, P, P, P, I32, P, I32, P]),
+        "vq2_resblock_bwd_data": (C.c_int, [I32, I32, I32, I32, I32, P, I32, P, I32, P, I32, P, P, P, I32, P, I32, P, P]),
+        "vq2_resblock_w2_workspace_bytes": (SZ, [I32, I32, I32, I32, I32]),
+        "vq2_resblock_w2_job_init": (C.c_int, [I32, I32, I32, I32, I32, P, P, P, C.POINTER(WgradJob)]),
         "vq2_resblock_fwd": (C.c_int, [I32, I32, I32, I32, I32, C.c_int, P, I32, P, P, P, P, P, I32, P, I32, P]),
         "vq2_slice_copy": (C.c_int, [P, I32, P, I32, I64, I32, C.c_int, P]),
         "vq2_vq_prepare": (C.c_int, [P, P, P, I32, I32, P]),

@@ -271,6 +271,8 @@ constexpr int GA_FLOATS = PROWS * LDA; // one g-patch slice buffer (also the siz
 constexpr int WA_FLOATS = CM * LDA;    // one slice of the 1x1 panel [32 cm][32 co]
 constexpr int WB_FLOATS = CC * LDA;    // one tap of the 3x3 panel [128 ci][32 cm]
 constexpr size_t LDS_BYTES = (size_t)(2 * GA_FLOATS + 2 * WA_FLOATS) * sizeof(float);   // 64,512
+constexpr int WR_FLOATS = 16 * 64 + 32;   // one wave's partial 32x32 tile of the 1x1 weight gradient + 32 bias partials
+constexpr size_t LDS_BYTES_W2 = LDS_BYTES + (size_t)4 * WR_FLOATS * sizeof(float);     // 81,408: still two per CU
 static_assert(GA_FLOATS + 2 * WB_FLOATS <= 2 * GA_FLOATS + 2 * WA_FLOATS, "phase-B buffers alias the phase-A ones");
 }  // namespace rbb
 
@@ -282,6 +284,8 @@ struct ResBwdParams {
     const float *w1d;  // VQ2_PACK_DGRAD panel of the 3x3 weight: [128 ci][9 flipped taps][32 cm]
     float *dh;         // [N,H,W,lddh]
     float *dx;         // [N,H,W,lddx]
+    float *w2_slab;    // [grid][128 co][32 cm] partial 1x1 weight gradients of each workgroup's own pixels, or null
+    float *b2_slab;    // [grid][128 co]        partial 1x1 bias gradients (with w2_slab)
     int N, H, W, ldg, ldr, ldx, lddh, lddx;
     int tiles_x, tiles_y;
     unsigned long long *stamps;   // diagnostic (vq2_debug_set_stamps): s_memtime at the phase boundaries of 2 workgroups
@@ -333,16 +337,13 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdP
     }
     const int wa_off = ((tid >> 3) * CC) * 4 + (tid & 7) * 16;          // row cm = tid>>3 of the [32][128] panel
     const int st8 = (tid >> 3) * LDA + (tid & 7) * 4;                   // LDS float offset of float4 number tid (+32 rows per j)
-    // ALL slices of the g patch are requested up front (phase A has the registers to itself: 4 x 7 float4 per
-    // thread): one memory round trip for the whole phase instead of one per slice -- the 16-32 MFMAs a wave
-    // runs per slice are far too few to hide a fetch behind.
     constexpr int NSA = CC / SA;
-    u32x4 rga[NSA][GA_LD], rwa[NSA];
+    u32x4 rga[GA_LD], rwa;
     auto issue_a = [&](int s) {
         const int soff = s * SA * 4;
 #pragma unroll
-        for (int j = 0; j < GA_LD; ++j) rga[s][j] = __builtin_amdgcn_raw_buffer_load_b128(rg, ga_off[j], soff, 0);
-        rwa[s] = __builtin_amdgcn_raw_buffer_load_b128(rw2, wa_off, soff, 0);
+        for (int j = 0; j < GA_LD; ++j) rga[j] = __builtin_amdgcn_raw_buffer_load_b128(rg, ga_off[j], soff, 0);
+        rwa = __builtin_amdgcn_raw_buffer_load_b128(rw2, wa_off, soff, 0);
     };
     auto store_a = [&](int s) {
         const int buf = s & 1;
@@ -350,8 +351,8 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdP
 #pragma unroll
         for (int j = 0; j < GA_LD; ++j)
             if ((j + 1) * 256 <= NPATCH * (SA / 4) || tid + 256 * j < NPATCH * (SA / 4))
-                *reinterpret_cast<float4 *>(a + j * 32 * LDA) = u4_as_f4(rga[s][j]);
-        *reinterpret_cast<float4 *>(Wa + buf * WA_FLOATS + st8) = u4_as_f4(rwa[s]);
+                *reinterpret_cast<float4 *>(a + j * 32 * LDA) = u4_as_f4(rga[j]);
+        *reinterpret_cast<float4 *>(Wa + buf * WA_FLOATS + st8) = u4_as_f4(rwa);
     };
     // this wave's patch row blocks: wq, and wq + 4 for waves 0 and 1 (6 blocks of 32 rows cover the 180 patch rows)
     const int nblk = wq < 2 ? 2 : 1;
@@ -373,6 +374,21 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdP
 #pragma unroll
         for (int q = 0; q < 16; ++q) accA[bi][q] = 0.f;
 
+    // Fused 1x1 weight gradient (w2_slab != null): dW2[co][cm] += sum over this tile's own pixels of g[px][co]*r[px][cm].
+    // Phase A has g in LDS one 32-channel slice at a time, so slice s yields the 32x32 block of output channels
+    // 32s..32s+31: every wave reduces over its own 32 pixels (16 MFMAs, A = g column from the slice buffer, B = r
+    // fragments held in registers for the whole phase), the four partial blocks meet in an LDS scratch, and each
+    // wave sums and stores a quarter.  Replaces a whole launch that re-read g and r from memory (HBM-bound).
+    const bool fuse_w2 = P.w2_slab != nullptr;
+    float *Wr = smem + 2 * GA_FLOATS + 2 * WA_FLOATS;      // [4 waves][WR_FLOATS], only allocated with fuse_w2
+    float rB[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        const int q = 2 * kk + (lane >> 5);                // this lane's pixel of MFMA step kk: tile row 2*wq + q/16
+        const int gy = y0 + 2 * wq + (q >> 4), gx = x0 + (q & 15);
+        const int pix = (gy < P.H && gx < P.W) ? (n * P.H + gy) * P.W + gx : -1;
+        rB[kk] = fuse_w2 ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, pix >= 0 ? pix * P.ldr * 4 + l31 * 4 : OOB, 0, 0)) : 0.f;
+    }
     // first tap panel of phase B: fetched behind the last phase-A slice
     const int wb_goff = ((tid >> 3) * 9 * CM) * 4 + (tid & 7) * 16;     // row ci = tid>>3 (+32 per j), tap 0
     u32x4 rwb[4];
@@ -385,15 +401,14 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdP
         for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(Wb + buf * WB_FLOATS + st8 + j * 32 * LDA) = u4_as_f4(rwb[j]);
     };
 
-#pragma unroll
-    for (int s = 0; s < NSA; ++s) issue_a(s);
+    issue_a(0);
     store_a(0);
     __syncthreads();
     stamp(1);
 #pragma unroll
     for (int s = 0; s < NSA; ++s) {
         const int buf = s & 1;
-        if (s + 1 == NSA) issue_b(0);
+        if (s + 1 < NSA) issue_a(s + 1); else issue_b(0);
         __builtin_amdgcn_sched_barrier(0);
         {
             const float *b = Wa + buf * WA_FLOATS + l31 * LDA + fk;
@@ -413,9 +428,41 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdP
                 }
             }
         }
+        if (fuse_w2) {
+            f32x16 aw;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) aw[r] = 0.f;
+            float bs = 0.f;
+            const float *ga = Ga + buf * GA_FLOATS + l31;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const int q = 2 * kk + (lane >> 5);
+                const float a = ga[((2 * wq + (q >> 4) + 1) * PW + (q & 15) + 1) * LDA];
+                aw = __builtin_amdgcn_mfma_f32_32x32x2f32(a, rB[kk], aw, 0, 0, 0);
+                bs += a;
+            }
+            float *wr = Wr + wq * WR_FLOATS;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wr[r * 64 + lane] = aw[r];
+            bs += __shfl_xor(bs, 32, 64);
+            if (lane < 32) wr[16 * 64 + lane] = bs;
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (s + 1 < NSA) store_a(s + 1);
         __syncthreads();
+        if (fuse_w2) {   // wave wq sums accumulator rows 4*wq..4*wq+3 of the four partial blocks; wave 0 the bias partials
+            float *slab = P.w2_slab + ((size_t)blockIdx.x * CC + s * 32) * CM;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * wq + i;
+                const float v = (Wr[r * 64 + lane] + Wr[WR_FLOATS + r * 64 + lane]) + (Wr[2 * WR_FLOATS + r * 64 + lane] + Wr[3 * WR_FLOATS + r * 64 + lane]);
+                slab[(rowq + (r & 3) + 8 * (r >> 2)) * CM + l31] = v;
+            }
+            if (wq == 0 && lane < 32)
+                P.b2_slab[(size_t)blockIdx.x * CC + s * 32 + lane] =
+                    (Wr[16 * 64 + lane] + Wr[WR_FLOATS + 16 * 64 + lane]) + (Wr[2 * WR_FLOATS + 16 * 64 + lane] + Wr[3 * WR_FLOATS + 16 * 64 + lane]);
+            __syncthreads();   // the scratch is rewritten by the next slice
+        }
     }
     stamp(2);
     // every wave is past its last phase-A fragment read: Dh and Wb may overwrite the slice buffers
@@ -559,9 +606,29 @@ extern "C" int vq2_resblock_fwd(int32_t N, int32_t H, int32_t W, int32_t C, int3
     return check_launch("resblock_fwd_kernel");
 }
 
+static int rb_grid(int N, int H, int W) { return N * ((W + vq2::rb::TW - 1) / vq2::rb::TW) * ((H + vq2::rb::TH - 1) / vq2::rb::TH); }
+
+extern "C" size_t vq2_resblock_w2_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cm) {
+    if (N <= 0 || H <= 0 || W <= 0 || !vq2_resblock_supported(C, Cm)) return 0;
+    return (size_t)rb_grid(N, H, W) * ((size_t)C * Cm + C) * sizeof(float);
+}
+
+extern "C" int vq2_resblock_w2_job_init(int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cm, const void *ws, float *dw,
+                                        float *db, vq2_wgrad_job *job) {
+    VQ2_REQUIRE(ws && dw && job && vq2_resblock_supported(C, Cm) && N > 0 && H > 0 && W > 0, "resblock_w2_job_init: bad arguments");
+    const int S = rb_grid(N, H, W);
+    const float *w = static_cast<const float *>(ws);
+    job->ws = w; job->dw = dw; job->bias_ws = db ? w + (size_t)S * C * Cm : nullptr; job->db = db;
+    job->unit_offset = 0;
+    job->O = C; job->I = Cm; job->Or = C; job->Ir = Cm; job->taps = 1; job->S = S;
+    job->n_units_w = (C * Cm + 31) / 32; job->n_units_b = db ? (C + 31) / 32 : 0;
+    job->swapped = 0; job->bias_splits = 0;
+    return VQ2_OK;
+}
+
 extern "C" int vq2_resblock_bwd_data(int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cm, const float *g, int32_t ldg,
                                      const float *r, int32_t ldr, const float *x, int32_t ldx, const float *w2d,
-                                     const float *w1d, float *dh, int32_t lddh, float *dx, int32_t lddx,
+                                     const float *w1d, float *dh, int32_t lddh, float *dx, int32_t lddx, void *w2_ws,
                                      vq2_stream_t stream) {
     using namespace vq2;
     VQ2_REQUIRE(N > 0 && H > 0 && W > 0, "resblock_bwd_data: empty tensor");
@@ -580,6 +647,7 @@ extern "C" int vq2_resblock_bwd_data(int32_t N, int32_t H, int32_t W, int32_t C,
     VQ2_REQUIRE(npix * ldmax * 4.0 < (double)rb::OOB, "resblock_bwd_data: tensors must be smaller than %d bytes", rb::OOB);
     ResBwdParams P{};
     P.g = g; P.r = r; P.x = x; P.w2d = w2d; P.w1d = w1d; P.dh = dh; P.dx = dx;
+    VQ2_REQUIRE(!w2_ws || aligned16(w2_ws), "resblock_bwd_data: workspace must be 16-byte aligned");
     P.N = N; P.H = H; P.W = W; P.ldg = ldg; P.ldr = ldr; P.ldx = ldx; P.lddh = lddh; P.lddx = lddx;
     P.tiles_x = (W + rb::TW - 1) / rb::TW; P.tiles_y = (H + rb::TH - 1) / rb::TH;
     const int grid = N * P.tiles_x * P.tiles_y;
@@ -588,7 +656,10 @@ extern "C" int vq2_resblock_bwd_data(int32_t N, int32_t H, int32_t W, int32_t C,
     const char *name = "resblock_bwd_data";
     if (prof_enabled()) name = prof_label("resblock_bwd_data|M=%d,C=%d,Cm=%d", N * H * W, C, Cm);
     ProfScope prof(name, 2.0 * npix * (9.0 * C * Cm + (double)Cm * C), 4.0 * npix * (4.0 * C + 2.0 * Cm), s);
-    allow_big_lds(resblock_bwd_data_kernel, rbb::LDS_BYTES);
-    hipLaunchKernelGGL(resblock_bwd_data_kernel, dim3(grid), dim3(256), rbb::LDS_BYTES, s, P);
+    P.w2_slab = static_cast<float *>(w2_ws);
+    P.b2_slab = w2_ws ? P.w2_slab + (size_t)grid * C * Cm : nullptr;
+    const size_t lds = w2_ws ? rbb::LDS_BYTES_W2 : rbb::LDS_BYTES;
+    allow_big_lds(resblock_bwd_data_kernel, lds);
+    hipLaunchKernelGGL(resblock_bwd_data_kernel, dim3(grid), dim3(256), lds, s, P);
     return check_launch("resblock_bwd_data_kernel");
 }

@@ -275,6 +275,25 @@ class WgradBatch:
         dw, db = ent["dw"], ent["db"]
         return dw.view_as(dw), (None if db is None else db.view_as(db))
 
+    def resblock_w2(self, n, h, w, c, cm, weight, bias):
+        """Workspace for the 1x1 weight/bias gradient that vq2_resblock_bwd_data leaves per workgroup; its job
+        joins the batched reduction like any other layer's slabs.  Returns (workspace tensor, dw view, db view)."""
+        key = (id(weight), n, h, w, "rbw2")
+        ent = self.entries.get(key)
+        if ent is None:
+            nbytes = lib.vq2_resblock_w2_workspace_bytes(n, h, w, c, cm)
+            ws = torch.empty(max(nbytes // 4, 4), device=weight.device, dtype=torch.float32)
+            dw, db = weight._vq2_grad, bias._vq2_grad
+            job = WgradJob()
+            check(lib.vq2_resblock_w2_job_init(n, h, w, c, cm, _p(ws), _p(dw), _p(db), C.byref(job)), "resblock_w2_job_init")
+            ent = {"ws": ws, "nbytes": nbytes, "job": job, "dw": dw, "db": db, "used": False}
+            self.entries[key] = ent
+            self.dirty = True
+        if not ent["used"]:
+            ent["used"] = True
+            self.order.append(key)
+        return ent["ws"], ent["dw"].view_as(ent["dw"]), ent["db"].view_as(ent["db"])
+
     def flush(self):
         if not self.order:
             return
@@ -555,9 +574,19 @@ class ResBlockFn(Function):
             # both data gradients in one launch (dh is recomputed on each tile's halo and kept in LDS)
             dh = torch.empty((n, h, w, s1.co), device=x.device, dtype=torch.float32)
             dx = torch.empty((n, h, w, c), device=x.device, dtype=torch.float32)
+            # with the deferred reduction active the same launch also produces the 1x1 conv's weight/bias gradient
+            # partials (it holds g and r anyway): no separate wgrad launch for conv[3]
+            batch = WGRAD_BATCH[0]
+            w2_ws = None
+            if (batch is not None and ctx.needs_input_grad[3] and ctx.needs_input_grad[4] and
+                    getattr(w2, "_vq2_grad", None) is not None and getattr(b2, "_vq2_grad", None) is not None):
+                w2_ws, dw2, db2 = batch.resblock_w2(n, h, w, c, s1.co, w2, b2)
             check(lib.vq2_resblock_bwd_data(n, h, w, c, s1.co, _p(g), ld_of(g), _p(r), ld_of(r), _p(x), ld_of(x),
                                             _p(packed_weight(s2, w2, PACK_DGRAD)), _p(packed_weight(s1, w1, PACK_DGRAD)),
-                                            _p(dh), ld_of(dh), _p(dx), ld_of(dx), _stream()), "resblock_bwd_data")
+                                            _p(dh), ld_of(dh), _p(dx), ld_of(dx), _p(w2_ws), _stream()), "resblock_bwd_data")
+            if w2_ws is not None:
+                dw1, db1 = conv_wgrad(s1, x, dh, True, w1, b1, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+                return dx, dw1, db1, dw2, db2, None, None, None, None, None
         else:
             # through conv1x1 and the inner ReLU (mask r > 0)
             dh = conv_dgrad(s2, r.shape, g, w2, mask=r)
