@@ -386,7 +386,8 @@ def test_thirty_step_trajectory_tracks_oracle(amd):
 
 def _step_vs_oracle(amd, cfg, size, batch, seed):
     st = O.make_state(cfg, seed)
-    m = amd.VQVAE(n_embed=cfg.n_embed)
+    m = amd.VQVAE(in_channel=cfg.in_channel, channel=cfg.channel, n_res_block=cfg.n_res_block,
+                  n_res_channel=cfg.n_res_channel, embed_dim=cfg.embed_dim, n_embed=cfg.n_embed)
     m.load_state_dict(st)
     m.to(dev())
     ids, qin = {}, {}
@@ -428,8 +429,9 @@ def _step_vs_oracle(amd, cfg, size, batch, seed):
                 gref = ref["grads"][k]
                 close(p.grad, gref, rtol=2e-3, atol=2e-4 * float(gref.abs().max()) + 1e-9, what=k + " (element-wise)")
     sd = m.state_dict()
+    last_bias = [k for k in st if k.startswith("dec.blocks.") and k.endswith(".bias")][-1]
     for k in ("quantize_t.cluster_size", "quantize_b.cluster_size", "quantize_b.embed_avg", "enc_b.blocks.0.weight",
-              "dec.blocks.6.bias"):
+              last_bias):
         close(sd[k], st[k], rtol=1e-3 if exact else 5e-2, atol=2e-5 if exact else 2e-2, what=k)
 
 
@@ -441,3 +443,11 @@ def test_config4_large_codebook_step_vs_oracle(amd):
 def test_config5_512px_step_vs_oracle(amd):
     """BASELINE configs[4] geometry: 512x512 images through the default two-level model."""
     _step_vs_oracle(amd, O.DEFAULT, 512, 1, 32)
+
+
+@pytest.mark.parametrize("n_res_block", [0, 3])
+def test_block_count_variants_step_vs_oracle(amd, n_res_block):
+    """Encoder/Decoder without ResBlocks (the trailing ReLU then fuses into a conv and its backward mask into the
+    consumers' dgrad launches) and with three of them: one train step vs the oracle, element-wise gradients."""
+    cfg = O.VQVAEConfig(channel=32, n_res_block=n_res_block, n_res_channel=8, embed_dim=16, n_embed=64)
+    _step_vs_oracle(amd, cfg, 32, 3, 41 + n_res_block)

@@ -356,6 +356,7 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdP
     };
     // this wave's patch row blocks: wq, and wq + 4 for waves 0 and 1 (6 blocks of 32 rows cover the 180 patch rows)
     const int nblk = wq < 2 ? 2 : 1;
+    issue_a(0);         // first in the queue: loads return in order, and only this slice gates the first MFMA
     int pixA[2];        // pixel of patch row 32*b + l31 (this lane's GEMM row), per block
     float rmask[2][16];
 #pragma unroll
@@ -401,7 +402,6 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdP
         for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(Wb + buf * WB_FLOATS + st8 + j * 32 * LDA) = u4_as_f4(rwb[j]);
     };
 
-    issue_a(0);
     store_a(0);
     __syncthreads();
     stamp(1);
