@@ -32,8 +32,13 @@ static inline hipStream_t to_stream(vq2_stream_t s) { return reinterpret_cast<hi
 
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// ReLU of freshly loaded values as ONE vector instruction each: fmaxf() on data straight from memory compiles to a
+// canonicalising v_max_f32(x, x) plus v_max_f32(0, x) (and LLVM folds v_med3 back to that) -- and every vector-ALU
+// instruction next to fp32 MFMAs costs matrix time.  On the bit pattern, max(int(x), 0) is the same function: negative
+// floats (and -0) are negative integers, non-negative floats keep their bits.
+__device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 __device__ __forceinline__ float4 relu4(float4 v) {
-    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    v.x = relu1(v.x); v.y = relu1(v.y); v.z = relu1(v.z); v.w = relu1(v.w);
     return v;
 }
 
