@@ -37,6 +37,8 @@ static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t
 // instruction next to fp32 MFMAs costs matrix time.  On the bit pattern, max(int(x), 0) is the same function: negative
 // floats (and -0) are negative integers, non-negative floats keep their bits.
 __device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+// optional ReLU without a select: floor = 0 (ReLU) or INT_MIN (identity)
+__device__ __forceinline__ float relu_floor(float x, int floor_bits) { return __int_as_float(max(__float_as_int(x), floor_bits)); }
 __device__ __forceinline__ float4 relu4(float4 v) {
     v.x = relu1(v.x); v.y = relu1(v.y); v.z = relu1(v.z); v.w = relu1(v.w);
     return v;

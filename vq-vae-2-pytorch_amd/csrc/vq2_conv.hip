@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256, (MT * NT == 4) ? (BK == 16 ? 3 : 2) : 1) void 
                     if (maskp && !P.mask_after) v = (mk[q] > 0.f) ? v : 0.f;
                     if (resp) v += rs[q];
                     if (maskp && P.mask_after) v = (mk[q] > 0.f) ? v : 0.f;
-                    if (P.relu_out) v = fmaxf(v, 0.f);
+                    v = relu_floor(v, P.relu_out ? 0 : (int)0x80000000);
                     if (ok[q]) yp[(size_t)pix[q] * P.ldy + co] = v;
                 }
             }
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256, OCC4 ? 4 : ((MT * NT == 4) ? (BK == 16 ? 3 : 2
                     if (mask_first) v = (mk[q] > 0.f) ? v : 0.f;
                     if (has_res) v += rs[q];
                     if (mask_last) v = (mk[q] > 0.f) ? v : 0.f;
-                    if (P.relu_out) v = fmaxf(v, 0.f);
+                    v = relu_floor(v, P.relu_out ? 0 : (int)0x80000000);
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, pix[q] >= 0 ? pix[q] * ldy4 + co4 : OOB, 0, 0);
                 }
             }
@@ -793,7 +793,7 @@ __global__ __launch_bounds__(256, 2) void subpixel_conv_kernel(const ConvGemmPar
                     if (mask_first) v = (mk[q] > 0.f) ? v : 0.f;
                     if (has_res) v += rs[q];
                     if (mask_last) v = (mk[q] > 0.f) ? v : 0.f;
-                    if (P.relu_out) v = fmaxf(v, 0.f);
+                    v = relu_floor(v, P.relu_out ? 0 : (int)0x80000000);
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, pb[q] >= 0 ? (pb[q] + poff) * ldy4 + co4 : SOOB, 0, 0);
                 }
             }

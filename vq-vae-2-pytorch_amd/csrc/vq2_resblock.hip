@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const ResFwdParams
         for (int r = 0; r < 16; ++r) {
             const int row = rowq + (r & 3) + 8 * (r >> 2);
             const int pix = __shfl(pix_lane, row, 64);
-            const float v = fmaxf(acc1[r] + bv, 0.f);
+            const float v = relu1(acc1[r] + bv);
             Rs[(32 * wq + row) * LDR + l31] = v;
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rr, pix >= 0 ? pix * ldr4 + l31 * 4 : OOB, 0, 0);
         }
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const ResFwdParams
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float v = acc2[j][r];
-            if (relu_out) v = fmaxf(v, 0.f);
+            v = relu_floor(v, relu_out ? 0 : (int)0x80000000);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, yoff[r] + j * 128, 0, 0);
         }
 }
