@@ -305,7 +305,8 @@ __device__ __forceinline__ float4 as_f4(u32x4 v) {
 // OCC4: four workgroups per CU (BK = 16, <= 128 VGPRs, exactly 40 KiB of LDS: the tap table is replaced by a
 // per-thread (kh, kw) counter) -- all 1,024 tiles of a 64x64-resolution layer are then resident at once: ONE
 // round, so one exposed prologue and one epilogue burst per launch instead of two.
-template <int WAVES_M, int WAVES_N, int MT, int NT, int BK, bool PIPE, bool RELU_IN, bool OCC4 = false>
+// UNI (Ci % BK == 0, K % BK == 0: every layer but the 3-channel ones): see the scalar k tracking below.
+template <int WAVES_M, int WAVES_N, int MT, int NT, int BK, bool PIPE, bool RELU_IN, bool OCC4 = false, bool UNI = OCC4>
 __global__ __launch_bounds__(256, OCC4 ? 4 : ((MT * NT == 4) ? (BK == 16 ? 3 : 2) : 1)) void conv_gemm_fast_kernel(const ConvGemmParams P) {
     constexpr int LDK = BK + 4;
     constexpr int BM = WAVES_M * MT * 32;
@@ -381,14 +382,14 @@ __global__ __launch_bounds__(256, OCC4 ? 4 : ((MT * NT == 4) ? (BK == 16 ? 3 : 2
     int tap = kglob / P.Ci;
     int ci = kglob - tap * P.Ci;
     const int tstep = BK / P.Ci, cstep = BK - tstep * P.Ci;
-    // OCC4 (Ci % BK == 0): every thread of the workgroup is in the SAME tap and 16-channel block of a chunk, so the
+    // UNI (Ci % BK == 0): every thread of the workgroup is in the SAME tap and BK-channel block of a chunk, so the
     // tap, its (kh, kw) and the channel base are tracked on the scalar unit; a thread only adds its own 4*lk bytes
     // (folded into a_base / b_base once).  ~25 vector instructions per chunk less next to the MFMAs.
     int u_tap = 0, u_kh = 0, u_kw = 0, u_cb = 0;
     bool b_ok[B_LD];
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) b_ok[j] = b_base[j] >= 0;
-    if (OCC4) {
+    if (UNI) {
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) a_base[j] += lk * 4;
 #pragma unroll
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(256, OCC4 ? 4 : ((MT * NT == 4) ? (BK == 16 ? 3 : 2
     // K % BK == 0 (every layer of this model): a chunk never runs past K, no tail predicate needed
     const bool k_aligned = (P.K % BK) == 0;
     auto prep_offsets = [&]() {
-        if constexpr (OCC4) {
+        if constexpr (UNI) {
             const int koff_s = ((u_kh * P.W + u_kw) * P.ldx + u_cb) * 4;     // scalar
             const int kb_s = (u_tap * P.Ci + u_cb) * 4;                      // scalar
 #pragma unroll
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(256, OCC4 ? 4 : ((MT * NT == 4) ? (BK == 16 ? 3 : 2
     };
     auto load_chunk = [&]() { prep_offsets(); issue_loads(); };
     auto advance_k = [&]() {
-        if constexpr (OCC4) {
+        if constexpr (UNI) {
             u_cb += BK;
             if (u_cb >= P.Ci) {
                 u_cb = 0; ++u_tap;
@@ -597,11 +598,12 @@ static int launch_conv_gemm_fast(const ConvGemmParams &P, hipStream_t s) {
     constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
     const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float) + (OCC4 ? 0 : 64 * sizeof(int));
     const unsigned nwg = ((P.M + BM - 1) / BM) * ((P.Co + BN - 1) / BN) * P.phases;
-    static const int pipe = tune("VQ2_PIPE", 1);
-    auto kern = P.relu_in ? (pipe ? conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, true, true, OCC4>
-                                  : conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, false, true, OCC4>)
-                          : (pipe ? conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, true, false, OCC4>
-                                  : conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, false, false, OCC4>);
+    // uniform k tracking whenever a chunk never straddles two taps (every layer except the 3-channel ones)
+    const bool uni = OCC4 || (P.Ci % BK == 0 && P.K % BK == 0);
+    auto kern = P.relu_in ? (uni ? conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, true, true, OCC4, true>
+                                 : conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, true, true, OCC4, OCC4>)
+                          : (uni ? conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, true, false, OCC4, true>
+                                 : conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, true, false, OCC4, OCC4>);
     allow_big_lds(kern, lds);
     dim3 grid(nwg);
     const char *name = "conv_gemm";
