@@ -177,22 +177,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
             for (int r = 0; r < WG_BKR; r += 2) { s0 += xcol[r * BNK]; s1 += xcol[(r + 1) * BNK]; }
             bsum += s0 + s1;
         }
-        const float *gs = Gs + buf * WG_BKR * BMO + fk * BMO + wm * MT * 32 + fr;
-        const float *xs = Xs + buf * WG_BKR * BNK + fk * BNK + wn * NT * 32 + fr;
+        // a wave's 32-wide blocks are INTERLEAVED with the other waves' (block i of wave wm = i*WAVES_M + wm): the two
+        // fragments of a k-step are then 256 bytes apart and k-steps 1 KiB apart -- one ds_read2st64_b32 with immediate
+        // offsets per operand and step, no vector add to rebuild a base (vector instructions cost matrix time)
+        const float *gs = Gs + buf * WG_BKR * BMO + fk * BMO + wm * 32 + fr;
+        const float *xs = Xs + buf * WG_BKR * BNK + fk * BNK + wn * 32 + fr;
         // fragments double-buffered: the ds_reads of k-step kk+1 are in flight during the MFMAs of step kk
         float fa[2][MT], fb[2][NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) fa[0][i] = gs[i * 32];
+        for (int i = 0; i < MT; ++i) fa[0][i] = gs[i * WAVES_M * 32];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) fb[0][j] = xs[j * 32];
+        for (int j = 0; j < NT; ++j) fb[0][j] = xs[j * WAVES_N * 32];
 #pragma unroll
         for (int kk = 0; kk < WG_BKR / 2; ++kk) {
             const int cur = kk & 1, nxt = cur ^ 1;
             if (kk + 1 < WG_BKR / 2) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i) fa[nxt][i] = gs[(kk + 1) * 2 * BMO + i * 32];
+                for (int i = 0; i < MT; ++i) fa[nxt][i] = gs[(kk + 1) * 2 * BMO + i * WAVES_M * 32];
 #pragma unroll
-                for (int j = 0; j < NT; ++j) fb[nxt][j] = xs[(kk + 1) * 2 * BNK + j * 32];
+                for (int j = 0; j < NT; ++j) fb[nxt][j] = xs[(kk + 1) * 2 * BNK + j * WAVES_N * 32];
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -216,11 +219,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
     const int colq = lane & 31, rowq = 4 * (lane >> 5);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int k = k0 + (wn * NT + j) * 32 + colq;
+        const int k = k0 + (j * WAVES_N + wn) * 32 + colq;
         if (k >= P.K) continue;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            const int ob = o0 + (wm * MT + i) * 32 + rowq;
+            const int ob = o0 + (i * WAVES_M + wm) * 32 + rowq;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = ob + (r & 3) + 8 * (r >> 2);
@@ -389,22 +392,25 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
             for (int r = 0; r < WG_BKR; r += 2) { s0 += xcol[r * BNK]; s1 += xcol[(r + 1) * BNK]; }
             bsum += s0 + s1;
         }
-        const float *gs = Gs + buf * WG_BKR * BMO + fk * BMO + wm * MT * 32 + fr;
-        const float *xs = Xs + buf * WG_BKR * BNK + fk * BNK + wn * NT * 32 + fr;
+        // a wave's 32-wide blocks are INTERLEAVED with the other waves' (block i of wave wm = i*WAVES_M + wm): the two
+        // fragments of a k-step are then 256 bytes apart and k-steps 1 KiB apart -- one ds_read2st64_b32 with immediate
+        // offsets per operand and step, no vector add to rebuild a base (vector instructions cost matrix time)
+        const float *gs = Gs + buf * WG_BKR * BMO + fk * BMO + wm * 32 + fr;
+        const float *xs = Xs + buf * WG_BKR * BNK + fk * BNK + wn * 32 + fr;
         // fragments double-buffered: the ds_reads of k-step kk+1 are in flight during the MFMAs of step kk
         float fa[2][MT], fb[2][NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) fa[0][i] = gs[i * 32];
+        for (int i = 0; i < MT; ++i) fa[0][i] = gs[i * WAVES_M * 32];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) fb[0][j] = xs[j * 32];
+        for (int j = 0; j < NT; ++j) fb[0][j] = xs[j * WAVES_N * 32];
 #pragma unroll
         for (int kk = 0; kk < WG_BKR / 2; ++kk) {
             const int cur = kk & 1, nxt = cur ^ 1;
             if (kk + 1 < WG_BKR / 2) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i) fa[nxt][i] = gs[(kk + 1) * 2 * BMO + i * 32];
+                for (int i = 0; i < MT; ++i) fa[nxt][i] = gs[(kk + 1) * 2 * BMO + i * WAVES_M * 32];
 #pragma unroll
-                for (int j = 0; j < NT; ++j) fb[nxt][j] = xs[(kk + 1) * 2 * BNK + j * 32];
+                for (int j = 0; j < NT; ++j) fb[nxt][j] = xs[(kk + 1) * 2 * BNK + j * WAVES_N * 32];
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -426,11 +432,11 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
     const int colq = lane & 31, rowq = 4 * (lane >> 5);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int k = k0 + (wn * NT + j) * 32 + colq;
+        const int k = k0 + (j * WAVES_N + wn) * 32 + colq;
         if (k >= P.K) continue;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            const int ob = o0 + (wm * MT + i) * 32 + rowq;
+            const int ob = o0 + (i * WAVES_M + wm) * 32 + rowq;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = ob + (r & 3) + 8 * (r >> 2);
