@@ -389,11 +389,20 @@ __global__ __launch_bounds__(256, OCC4 ? 4 : ((MT * NT == 4) ? (BK == 16 ? 3 : 2
     bool b_ok[B_LD];
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) b_ok[j] = b_base[j] >= 0;
+    // ... and "out of the image / not a weight row" becomes an ADDITIVE 2^31 (refreshed for the A rows only when the
+    // tap changes): base + scalar + penalty is one v_add3 per load, no compare / select.  As an unsigned buffer offset
+    // anything >= 2^31 - (tensor bytes) is out of range; the launcher takes this path only for tensors below 1 GiB.
+    int a_pen[A_LD];
+    auto refresh_pen = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) a_pen[j] = ((a_vw[j] >> u_tap) & 1u) ? 0 : (int)0x80000000;
+    };
     if (UNI) {
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) a_base[j] += lk * 4;
 #pragma unroll
-        for (int j = 0; j < B_LD; ++j) b_base[j] += lk * 4;
+        for (int j = 0; j < B_LD; ++j) b_base[j] = b_ok[j] ? b_base[j] + lk * 4 : (int)0x80000000;
+        refresh_pen();
     }
     __syncthreads();  // tap table visible
 
@@ -409,9 +418,9 @@ __global__ __launch_bounds__(256, OCC4 ? 4 : ((MT * NT == 4) ? (BK == 16 ? 3 : 2
             const int koff_s = ((u_kh * P.W + u_kw) * P.ldx + u_cb) * 4;     // scalar
             const int kb_s = (u_tap * P.Ci + u_cb) * 4;                      // scalar
 #pragma unroll
-            for (int j = 0; j < A_LD; ++j) off_a[j] = ((a_vw[j] >> u_tap) & 1u) ? a_base[j] + koff_s : OOB;
+            for (int j = 0; j < A_LD; ++j) off_a[j] = a_base[j] + koff_s + a_pen[j];
 #pragma unroll
-            for (int j = 0; j < B_LD; ++j) off_b[j] = b_ok[j] ? b_base[j] + kb_s : OOB;
+            for (int j = 0; j < B_LD; ++j) off_b[j] = b_base[j] + kb_s;
             return;
         }
         const bool kv = k_aligned || tap < ntaps;
@@ -438,6 +447,7 @@ __global__ __launch_bounds__(256, OCC4 ? 4 : ((MT * NT == 4) ? (BK == 16 ? 3 : 2
             if (u_cb >= P.Ci) {
                 u_cb = 0; ++u_tap;
                 if (++u_kw == P.KW) { u_kw = 0; ++u_kh; }
+                refresh_pen();
             }
             return;
         }
@@ -599,7 +609,9 @@ static int launch_conv_gemm_fast(const ConvGemmParams &P, hipStream_t s) {
     const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float) + (OCC4 ? 0 : 64 * sizeof(int));
     const unsigned nwg = ((P.M + BM - 1) / BM) * ((P.Co + BN - 1) / BN) * P.phases;
     // uniform k tracking whenever a chunk never straddles two taps (every layer except the 3-channel ones)
-    const bool uni = OCC4 || (P.Ci % BK == 0 && P.K % BK == 0);
+    const long gib = 1L << 30;
+    const bool small = (long)P.N * P.H * P.W * P.ldx * 4 < gib && (long)P.Co * P.K * P.phases * 4 < gib;
+    const bool uni = small && (OCC4 || (P.Ci % BK == 0 && P.K % BK == 0));
     auto kern = P.relu_in ? (uni ? conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, true, true, OCC4, true>
                                  : conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, true, true, OCC4, OCC4>)
                           : (uni ? conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, true, false, OCC4, true>
@@ -892,7 +904,8 @@ static int run_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
             if (t128 == 1) return launch_conv_gemm_fast<2, 2, 2, 2, 16>(P, s);   // 3 workgroups per CU
             // 513..1024 tiles (every 64x64-resolution layer at batch 32): four workgroups per CU hold ALL tiles at
             // once -- one round instead of two in lock-step (measured +1..3 % per launch, 7.30 -> 7.23 ms/step)
-            if (P.Ci % 16 == 0 && (t128 == 2 || (t128 == 0 && wgs128 > 512 && wgs128 <= 1024)))
+            const bool below_gib = (long)P.N * P.H * P.W * P.ldx * 4 < (1L << 30) && (long)P.Co * P.K * P.phases * 4 < (1L << 30);
+            if (P.Ci % 16 == 0 && below_gib && (t128 == 2 || (t128 == 0 && wgs128 > 512 && wgs128 <= 1024)))
                 return launch_conv_gemm_fast<2, 2, 2, 2, 16, true>(P, s);
             return launch_conv_gemm_fast<2, 2, 2, 2, 32>(P, s);
         }
