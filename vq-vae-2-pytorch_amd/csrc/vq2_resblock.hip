@@ -143,19 +143,26 @@ __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const ResFwdParams
     auto compute = [&](int buf) {
         const float *a0 = As + buf * A_FLOATS + a_frag;
         const float *b0 = Bs + buf * B_FLOATS + b_frag;
+        // fragment pairs double-buffered by hand: pair p+1 is requested before the four MFMAs of pair p (left to itself
+        // the compiler reuses one register set and waits for every pair in front of its MFMAs)
+        constexpr int NP = 9 * (CS / 8);
+        float4 fa[2], fb[2];
+        fa[0] = *reinterpret_cast<const float4 *>(a0);
+        fb[0] = *reinterpret_cast<const float4 *>(b0);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const float *a = a0 + ((tap / 3) * PW + (tap % 3)) * LDK;
-            const float *b = b0 + tap * 32 * LDK;
-#pragma unroll
-            for (int k8 = 0; k8 < CS / 8; ++k8) {
-                const float4 fa = *reinterpret_cast<const float4 *>(a + 8 * k8);
-                const float4 fb = *reinterpret_cast<const float4 *>(b + 8 * k8);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc1, 0, 0, 0);
+        for (int p = 0; p < NP; ++p) {
+            const int cur = p & 1, nxt = cur ^ 1;
+            if (p + 1 < NP) {
+                const int tap = (p + 1) / (CS / 8), k8 = (p + 1) % (CS / 8);
+                fa[nxt] = *reinterpret_cast<const float4 *>(a0 + ((tap / 3) * PW + (tap % 3)) * LDK + 8 * k8);
+                fb[nxt] = *reinterpret_cast<const float4 *>(b0 + tap * 32 * LDK + 8 * k8);
             }
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].x, fb[cur].x, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].y, fb[cur].y, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].z, fb[cur].z, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].w, fb[cur].w, acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // next pair's two LDS reads first ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // ... then this pair's MFMAs
         }
     };
 
