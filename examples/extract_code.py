@@ -1,11 +1,14 @@
 """Encode-only export on the MI355X path (/root/reference/extract_code.py:14-33, 59-68).
 
-model.eval() -> model.encode(img) -> (id_t [B,H/8,W/8], id_b [B,H/4,W/4]) int64.  The reference pickles
-CodeRow(top, bottom, filename) rows keyed str(index) plus a 'length' key into LMDB (dataset.py:11,
-36-51); lmdb is not installed here, so the same rows go to one .npz (top, bottom, filename arrays) --
-format pinned from the reference's code only.
+model.eval() -> model.encode(img) -> (id_t [B,H/8,W/8], id_b [B,H/4,W/4]) int64, written as the reference's rows:
+pickle.dumps(CodeRow(top, bottom, filename)) under str(index) keys plus a 'length' key (dataset.py:11, 36-51;
+vqvae2_amd/codes.py).  The container is LMDB when `lmdb` is importable, else one sqlite3 file with the same keys
+and the same value bytes.
 
-    python examples/extract_code.py --ckpt checkpoint/vqvae_001.pt --path images_dir --name codes.npz
+Images: class sub-folders of image files like the reference's ImageFolder (resize, centre crop, [-1,1]
+normalisation: extract_code.py:46-53) when PIL can open them, or .npy batches [N,3,H,W] float32 already normalised.
+
+    python examples/extract_code.py --ckpt checkpoint/vqvae_001.pt --name codes.db images_dir
 """
 import argparse
 import glob
@@ -17,6 +20,49 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vqvae2_amd  # noqa: E402
+from vqvae2_amd import codes  # noqa: E402
+
+IMG_EXT = (".png", ".jpg", ".jpeg", ".bmp", ".webp")
+
+
+def image_batches(path, size, batch=128):
+    """ImageFolder order (sorted classes, sorted files); filename = class/file (dataset.py:14-22)."""
+    from PIL import Image
+    files = []
+    for cls in sorted(d for d in os.listdir(path) if os.path.isdir(os.path.join(path, d))):
+        for root, _, names in sorted(os.walk(os.path.join(path, cls))):
+            files += [(os.path.join(root, n), os.path.join(cls, n)) for n in sorted(names) if n.lower().endswith(IMG_EXT)]
+    for i in range(0, len(files), batch):
+        arrs = []
+        for full, _ in files[i:i + batch]:
+            im = Image.open(full).convert("RGB")
+            w, h = im.size
+            s = size / min(w, h)                                                     # transforms.Resize(size)
+            im = im.resize((max(size, round(w * s)), max(size, round(h * s))), Image.BILINEAR)
+            w, h = im.size
+            left, top = (w - size) // 2, (h - size) // 2                            # transforms.CenterCrop(size)
+            a = np.asarray(im.crop((left, top, left + size, top + size)), np.float32) / 255.0
+            arrs.append((a.transpose(2, 0, 1) - 0.5) / 0.5)                          # ToTensor + Normalize(0.5, 0.5)
+        yield torch.from_numpy(np.stack(arrs)), [name for _, name in files[i:i + batch]]
+
+
+def npy_batches(path):
+    for f in sorted(glob.glob(os.path.join(path, "*.npy"))):
+        arr = np.load(f)
+        yield torch.from_numpy(arr).float(), [f"{os.path.basename(f)}:{i}" for i in range(arr.shape[0])]
+
+
+def extract(store, loader, model, device):
+    """extract_code.py:14-33."""
+    index = 0
+    for img, filename in loader:
+        img = img.to(device)
+        _, _, _, id_t, id_b = model.encode(img)
+        id_t = id_t.detach().cpu().numpy()
+        id_b = id_b.detach().cpu().numpy()
+        index = codes.write_code_rows(store, id_t, id_b, filename, start=index)
+    store.put("length".encode("utf-8"), str(index).encode("utf-8"))
+    return index
 
 
 def main():
@@ -24,23 +70,18 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--ckpt", type=str, required=True)
     ap.add_argument("--name", type=str, required=True)
-    ap.add_argument("--path", type=str, required=True, help="directory of .npy batches [N,3,H,W] float32")
+    ap.add_argument("path", type=str)
     args = ap.parse_args()
     device = torch.device("cuda:0")
     model = vqvae2_amd.VQVAE()
-    model.load_state_dict(torch.load(args.ckpt, map_location="cpu", weights_only=True))
-    model = model.to(device).eval()                           # extract_code.py:59-62
-    tops, bottoms, names = [], [], []
-    with torch.no_grad():
-        for f in sorted(glob.glob(os.path.join(args.path, "*.npy"))):
-            img = torch.from_numpy(np.load(f)).float().to(device)
-            _, _, _, id_t, id_b = model.encode(img)           # extract_code.py:23
-            tops.append(id_t.cpu().numpy())
-            bottoms.append(id_b.cpu().numpy())
-            names += [f"{os.path.basename(f)}:{i}" for i in range(img.shape[0])]
-    np.savez_compressed(args.name, top=np.concatenate(tops), bottom=np.concatenate(bottoms),
-                        filename=np.array(names), length=len(names))
-    print(f"wrote {len(names)} code rows to {args.name}")
+    sd = torch.load(args.ckpt, map_location="cpu", weights_only=True)
+    model.load_state_dict({(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()})
+    model = model.to(device).eval()                            # extract_code.py:59-62
+    has_npy = bool(glob.glob(os.path.join(args.path, "*.npy")))
+    loader = npy_batches(args.path) if has_npy else image_batches(args.path, args.size)
+    with torch.no_grad(), codes.CodeStore(args.name, "w") as store:
+        n = extract(store, loader, model, device)
+    print(f"inserted: {n} rows into {args.name}")
 
 
 if __name__ == "__main__":

@@ -7,6 +7,10 @@ aggregated over ranks).  The re-ID parts of the fork are out of scope.  Data: a 
 image batches ([N,3,H,W] float32, already normalised) or, without --path, synthetic N(0,1) images
 (there is no torchvision / dataset access in this environment).
 
+Every rank runs the SAME number of steps: the batches found under --path are dealt round-robin and the
+remainder that would give some ranks one step more is dropped (what DistributedSampler's equal shards do for
+the reference), and the CycleScheduler's n_iter is that per-rank count x epochs (train_vqvae.py:189-195).
+
     python examples/train_stage1.py --size 256 --batch_size 32 --epoch 1 --iters 50
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train_stage1.py ...
 """
@@ -17,24 +21,31 @@ import sys
 
 import numpy as np
 import torch
-import torch.distributed as tdist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vqvae2_amd  # noqa: E402
 from vqvae2_amd import distributed as dist  # noqa: E402
 
 
-def batches(args, rank, world, device):
-    if args.path:
-        files = sorted(glob.glob(os.path.join(args.path, "*.npy")))[rank::world]
-        for f in files:
-            arr = torch.from_numpy(np.load(f)).float()
-            for i in range(0, arr.shape[0] - args.batch_size + 1, args.batch_size):
-                yield arr[i:i + args.batch_size].to(device, non_blocking=True)
-    else:
-        g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-        for _ in range(args.iters):
-            yield torch.randn(args.batch_size, 3, args.size, args.size, generator=g).to(device)
+def plan_batches(args, rank, world):
+    """-> list of (file, first row) this rank trains on per epoch (None = synthetic), equal length on every rank."""
+    if not args.path:
+        return [None] * args.iters
+    every = []
+    for f in sorted(glob.glob(os.path.join(args.path, "*.npy"))):
+        rows = np.load(f, mmap_mode="r").shape[0]
+        every += [(f, i) for i in range(0, rows - args.batch_size + 1, args.batch_size)]
+    common = len(every) // world
+    if common == 0:
+        raise SystemExit(f"{len(every)} batches of {args.batch_size} under {args.path}: fewer than the {world} ranks")
+    return every[rank::world][:common]
+
+
+def load_batch(item, args, gen, device):
+    if item is None:
+        return torch.randn(args.batch_size, 3, args.size, args.size, generator=gen).to(device)
+    f, i = item
+    return torch.from_numpy(np.ascontiguousarray(np.load(f, mmap_mode="r")[i:i + args.batch_size])).float().to(device)
 
 
 def main():
@@ -52,32 +63,32 @@ def main():
     ap.add_argument("--out", default="checkpoint")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
+    rank, local_rank, world = dist.bringup("nccl")             # launch.py:52-92 (RCCL group + device binding)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        tdist.init_process_group("nccl", device_id=device)
-    rank = dist.get_rank()
 
+    # every rank may build its model from its own RNG state: the trainer broadcasts rank 0's (DDP, train_vqvae.py:166-171)
     model = vqvae2_amd.VQVAE().to(device)
-    if args.resume:                                           # train_vqvae.py:173-182
-        sd = torch.load(args.resume, map_location="cpu", weights_only=True)
-        sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}
-        model.load_state_dict(sd)
-    n_iter = (args.iters if not args.path else max(1, len(glob.glob(os.path.join(args.path, "*.npy"))))) * args.epoch
-    trainer = vqvae2_amd.Stage1Trainer(model, lr=args.lr, sched=args.sched, n_iter=n_iter)
+    plan = plan_batches(args, rank, world)
+    trainer = vqvae2_amd.Stage1Trainer(model, lr=args.lr, sched=args.sched, n_iter=len(plan) * args.epoch)
+    first_epoch = 0
+    if args.resume:                                            # train_vqvae.py:173-182
+        sd = torch.load(args.resume, map_location=device, weights_only=True)
+        trainer.load_state_dict(sd)                            # bare model state_dict or a trainer checkpoint
+        first_epoch = int(sd.get("epoch", 0)) if "model" in sd else 0
+        if dist.is_primary():
+            print(f"==> loaded checkpoint {args.resume} (epoch {first_epoch})")
 
-    for epoch in range(args.epoch):
+    gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    for epoch in range(first_epoch, args.epoch):
         mse_sum = torch.zeros(2, device=device)                # (sum of recon * batch, count)
-        for i, img in enumerate(batches(args, rank, world, device)):
+        for i, item in enumerate(plan):
+            img = load_batch(item, args, gen, device)
             out = trainer.step(img)
             mse_sum[0] += out["recon"] * img.shape[0]
             mse_sum[1] += img.shape[0]
             if i % 25 == 0:
                 agg = mse_sum.clone()
-                dist.all_reduce(agg)                          # replaces the pickled all_gather of train_vqvae.py:93-100
+                dist.all_reduce(agg)                           # replaces the pickled all_gather of train_vqvae.py:93-100
                 if dist.is_primary():
                     lr = trainer.optimizer.param_groups[0]["lr"]
                     print(f"epoch: {epoch + 1}; it {i}; mse: {float(out['recon']):.5f}; "
@@ -85,9 +96,14 @@ def main():
                           flush=True)
         if dist.is_primary() and (epoch % 10 == 0 or epoch == args.epoch - 1):   # train_vqvae.py:205-206
             os.makedirs(args.out, exist_ok=True)
-            torch.save(model.state_dict(), os.path.join(args.out, f"vqvae_{str(epoch + 1).zfill(3)}.pt"))
-    if world > 1:
-        tdist.destroy_process_group()
+            tag = str(epoch + 1).zfill(3)
+            torch.save(model.state_dict(), os.path.join(args.out, f"vqvae_{tag}.pt"))       # the reference's file
+            full = trainer.state_dict()
+            full["epoch"] = epoch + 1
+            torch.save(full, os.path.join(args.out, f"trainer_{tag}.pt"))                   # exact-resume extras
+    dist.synchronize()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

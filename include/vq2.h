@@ -198,8 +198,10 @@ int vq2_slice_copy(const float *src, int32_t lds, float *dst, int32_t ldd, int64
  * vq2_vq_fwd:  idx[M] (int64) = first argmin_k ||x||^2 - 2 x.e_k + ||e_k||^2 (vqvae.py:44-49)
  *              out[M,D] = x + (e_idx - x)                            (vqvae.py:52,73)
  *              loss_partial: per-workgroup sums of (e_idx - x)^2     (vqvae.py:72)
- *              counts[K] += one-hot sum, sumsT[K,D] += scatter of x  (vqvae.py:55-56), if non-NULL
- *              (counts/sumsT must be zeroed by the caller; float atomics)
+ * vq2_vq_stats: counts[K] = one-hot sum, sumsT[K,D] = x rows summed per code   (vqvae.py:55-56)
+ *              every element is WRITTEN (no zeroing by the caller) and the result is bit-reproducible:
+ *              a stable counting sort of the row numbers by code, then each code's rows are added in
+ *              increasing row order along a fixed tree -- no float atomics.  ws >= vq2_vq_stats_workspace_bytes.
  * vq2_vq_loss: diff = sum(loss_partial) / (M*D)
  * vq2_vq_bwd:  dx = g_out + (2/(M*D)) * g_diff * (x - e_idx)         (autograd of vqvae.py:72-73)
  * vq2_vq_ema_update: in-place EMA of cluster_size/embed_avg/embed from (all-reduced) counts/sumsT
@@ -209,8 +211,10 @@ int vq2_slice_copy(const float *src, int32_t lds, float *dst, int32_t ldd, int64
 int vq2_vq_prepare(const float *embed, float *embedT, float *enorm, int32_t D, int32_t K, vq2_stream_t stream);
 size_t vq2_vq_fwd_workspace_floats(int64_t M);
 int vq2_vq_fwd(const float *x, int32_t ldx, const float *embed, const float *embedT, const float *enorm, int64_t M,
-               int32_t D, int32_t K, int64_t *idx, float *out, int32_t ldo, float *loss_partial, float *counts,
-               float *sumsT, vq2_stream_t stream);
+               int32_t D, int32_t K, int64_t *idx, float *out, int32_t ldo, float *loss_partial, vq2_stream_t stream);
+size_t vq2_vq_stats_workspace_bytes(int64_t M, int32_t D, int32_t K);
+int vq2_vq_stats(const float *x, int32_t ldx, const int64_t *idx, int64_t M, int32_t D, int32_t K, float *counts,
+                 float *sumsT, void *ws, size_t ws_bytes, vq2_stream_t stream);
 int vq2_vq_loss(const float *loss_partial, int64_t M, int32_t D, float *diff, vq2_stream_t stream);
 int vq2_vq_bwd(const float *g_out, int32_t ldg, const float *g_diff, const float *x, int32_t ldx,
                const int64_t *idx, const float *embedT, int64_t M, int32_t D, int32_t K, float *dx, int32_t lddx,

@@ -20,7 +20,7 @@ import vqvae as ref  # noqa: E402  (the reference module)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import rng  # noqa: E402
 from oracle import vqvae_oracle as O  # noqa: E402
-from oracle.make_golden_cases import (BLOCK_CASES, CONV_FLAVOURS, SEED, block_state,  # noqa: E402
+from oracle.make_golden_cases import (BLOCK_CASES, CONV_FLAVOURS, SCHED_CASES, SEED, block_state,  # noqa: E402
                                       conv_inputs, quantize_inputs)
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
@@ -213,10 +213,31 @@ def gen_full256():
     np.savez_compressed(os.path.join(OUT, "full256.npz"), **d)
 
 
+def gen_scheduler():
+    """(lr, momentum) trajectories of the reference's CycleScheduler (scheduler.py:251-320) driving a stock Adam."""
+    import scheduler as ref_sched   # /root/reference/scheduler.py
+    d = {}
+    for tag, kw, steps in SCHED_CASES:
+        opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+        s = ref_sched.CycleScheduler(opt, **kw)
+        lrs, moms, group_lr, group_b1 = [], [], [], []
+        for _ in range(steps):
+            lr, mom = s.step()
+            lrs.append(lr)
+            moms.append(np.nan if mom is None else mom)
+            group_lr.append(opt.param_groups[0]["lr"])
+            group_b1.append(opt.param_groups[0]["betas"][0])
+        d[f"{tag}.lr"] = np.asarray(lrs, np.float64)
+        d[f"{tag}.momentum"] = np.asarray(moms, np.float64)
+        d[f"{tag}.group_lr"] = np.asarray(group_lr, np.float64)
+        d[f"{tag}.group_beta1"] = np.asarray(group_b1, np.float64)
+    np.savez_compressed(os.path.join(OUT, "scheduler.npz"), **d)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["quantize", "convs", "blocks", "tiny", "single", "full"]
+    which = sys.argv[1:] or ["quantize", "convs", "blocks", "tiny", "single", "full", "scheduler"]
     if "quantize" in which:
         gen_quantize()
     if "convs" in which:
@@ -229,5 +250,7 @@ if __name__ == "__main__":
         gen_single_level()
     if "full" in which:
         gen_full256()
+    if "scheduler" in which:
+        gen_scheduler()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

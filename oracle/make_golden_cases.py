@@ -93,3 +93,13 @@ def block_state(tag, kind, args):
             a = rng.uniform(SEED, f"{tag}.{k}", shape, -0.1, 0.1)
         st[k] = torch.from_numpy(np.ascontiguousarray(a.astype(np.float32)))
     return st
+
+
+# CycleScheduler trajectories captured from the reference's scheduler.py (tag, ctor kwargs, number of steps);
+# "stage1" is exactly what train_vqvae.py:188-195 builds
+SCHED_CASES = [
+    ("stage1", dict(lr_max=3e-4, n_iter=450, momentum=None, warmup_proportion=0.05), 1000),
+    ("defaults", dict(lr_max=1e-3, n_iter=100), 250),
+    ("cos_linear", dict(lr_max=1e-2, n_iter=37, momentum=(0.9, 0.8), divider=10, warmup_proportion=0.5,
+                        phase=("cos", "linear")), 120),
+]

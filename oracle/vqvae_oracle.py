@@ -228,6 +228,18 @@ def quantize_margin(x, embed):
     return (two[:, 0] - two[:, 1]), d.argmin(1)
 
 
+def quantize_margin_chunked(x, embed, rows=8192):
+    """quantize_margin in row blocks: the [M,K] fp64 distance matrix of a full-size case (M = 131,072,
+    K = 8,192 -> 8.6 GB) never exists; same results."""
+    flat = x.reshape(-1, embed.shape[0])
+    margins, idxs = [], []
+    for r0 in range(0, flat.shape[0], rows):
+        mg, ix = quantize_margin(flat[r0:r0 + rows], embed)
+        margins.append(mg)
+        idxs.append(ix)
+    return torch.cat(margins), torch.cat(idxs)
+
+
 # --------------------------------------------------------------------------
 # conv stacks (vqvae.py:81-166)
 # --------------------------------------------------------------------------

@@ -1,0 +1,57 @@
+"""GPU: the RCCL path on the one GPU of the test box.  A fresh child under torch.distributed.run (--nproc-per-node 1,
+backend "nccl") runs Stage1Trainer with VQ2_DP_FORCE=1 -- group init + device binding, initial broadcast, the tail
+bucket from the backward hook and the head bucket on the side stream -- and must reproduce the plain
+single-process run BIT FOR BIT (a one-rank all-reduce is the identity, and the step has no float atomics).
+bench.py goes through the same launcher once."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _torchrun(script_args, extra_env):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port())] + script_args
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_trainer_over_rccl_world1_equals_plain_run(tmp_path):
+    import vqvae2_amd
+    from tests._train_cases import CASES, run_case
+    r = _torchrun([os.path.join(ROOT, "tests", "_rccl_child.py"), str(tmp_path)], {"VQ2_DP_FORCE": "1"})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    info = json.load(open(tmp_path / "info.json"))
+    for case, (cfg, size, batch, steps, seed) in CASES.items():
+        sd, losses, tr = run_case(vqvae2_amd, case)
+        assert not tr.dp
+        assert info[case]["early"] == steps, "the overlapped tail bucket must go out from the backward hook every step"
+        assert info[case]["losses"] == losses
+        got = np.load(tmp_path / f"{case}.npz")
+        for k, v in sd.items():
+            assert np.array_equal(got[k], v), f"{case}: {k} differs between the RCCL path and the plain path"
+
+
+def test_bench_under_torchrun_with_rccl_group():
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "tiny",
+                   "--no-cpu-baseline"], {"VQ2_DP_FORCE": "1"})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    assert line["collectives"]["backend"] == "nccl" and line["collectives"]["early_tail_buckets"] == 4

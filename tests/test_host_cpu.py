@@ -37,7 +37,9 @@ def test_invalid_arguments_are_rejected_without_gpu(amd):
     d.N, d.H, d.W, d.Ci, d.Co, d.KH, d.KW, d.stride, d.pad, d.ldx, d.ldy = 1, 8, 8, 6, 8, 3, 3, 1, 1, 8, 8
     assert lib.vq2_conv_fwd(ctypes.byref(d), 0, None, None, None, None, 0, None, None) == 1
     assert b"multiples of 4" in lib.vq2_last_error()
-    assert lib.vq2_vq_fwd(None, 0, None, None, None, 0, 0, 0, None, None, 0, None, None, None, None) == 1
+    assert lib.vq2_vq_fwd(None, 0, None, None, None, 0, 0, 0, None, None, 0, None, None) == 1
+    assert lib.vq2_vq_stats(None, 0, None, 0, 0, 0, None, None, None, 0, None) == 1
+    assert lib.vq2_vq_stats_workspace_bytes(131072, 64, 8192) > 131072 * 8
     assert lib.vq2_adam_step(None, None, None, None, 0, 1e-3, .9, .999, 1e-8, 1, 1.0, None) == 1
     with pytest.raises(RuntimeError):
         amd._lib.check(1, "x")
@@ -80,6 +82,91 @@ def test_cycle_scheduler_matches_oracle(amd):
     s2 = amd.CycleScheduler(opt, 1e-3, n_iter=10)
     lrs = [s2.step() for _ in range(10)]
     assert abs(lrs[2][0] - 1e-3) < 1e-12 and abs(lrs[2][1] - 0.85) < 1e-12
+
+
+def test_cycle_scheduler_matches_reference_golden(amd, golden):
+    """Trajectories captured from the reference's scheduler.py (oracle/make_golden.py gen_scheduler), for the
+    product scheduler AND the oracle's restatement; then an exact resume from state_dict()."""
+    from oracle.make_golden_cases import SCHED_CASES
+    import numpy as np
+    g = golden("scheduler")
+    for tag, kw, steps in SCHED_CASES:
+        opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+        s = amd.CycleScheduler(opt, **kw)
+        lrs, moms = [], []
+        for i in range(steps):
+            lr, mom = s.step()
+            lrs.append(lr)
+            moms.append(np.nan if mom is None else mom)
+            assert opt.param_groups[0]["lr"] == lr
+            np.testing.assert_allclose(opt.param_groups[0]["betas"][0], g[f"{tag}.group_beta1"][i], rtol=1e-12)
+        np.testing.assert_allclose(lrs, g[f"{tag}.lr"], rtol=1e-10, atol=0)
+        np.testing.assert_allclose(moms, g[f"{tag}.momentum"], rtol=1e-12, equal_nan=True)
+    tag, kw, steps = SCHED_CASES[0]
+    o = O.CycleSchedule(kw["lr_max"], kw["n_iter"], warmup_proportion=kw["warmup_proportion"])
+    np.testing.assert_allclose([o.step() for _ in range(steps)], g[f"{tag}.lr"], rtol=1e-12, atol=0)
+    # resume: 123 steps, save, fresh scheduler, load, continue == uninterrupted
+    opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    a = amd.CycleScheduler(opt, **kw)
+    for _ in range(123):
+        a.step()
+    b = amd.CycleScheduler(opt, **kw)
+    b.load_state_dict(a.state_dict())
+    np.testing.assert_allclose([b.step()[0] for _ in range(400)], g[f"{tag}.lr"][123:523], rtol=1e-10, atol=0)
+    with pytest.raises(ZeroDivisionError):      # the reference divides by an empty warm-up phase on its first step
+        amd.CycleScheduler(opt, 1e-3, n_iter=10, warmup_proportion=0.05).step()
+
+
+def test_code_rows_are_the_reference_pickles(amd, tmp_path):
+    """extract_code.py:27-33 / dataset.py:11,36-51: rows are pickle.dumps(CodeRow(top, bottom, filename)) under
+    str(index) keys plus a 'length' key.  The expected bytes are built here from the field spec alone."""
+    import collections
+    import pickle
+    import sys
+    import types
+    import numpy as np
+    from vqvae2_amd import codes
+    top = np.arange(12, dtype=np.int64).reshape(3, 4)
+    bottom = np.arange(48, dtype=np.int64).reshape(6, 8) * 3
+    mod = types.ModuleType("dataset")
+    mod.CodeRow = collections.namedtuple("CodeRow", ["top", "bottom", "filename"])
+    mod.CodeRow.__module__ = "dataset"
+    assert "dataset" not in sys.modules
+    sys.modules["dataset"] = mod
+    try:
+        want = pickle.dumps(mod.CodeRow(top=top, bottom=bottom, filename="cls/img_0.png"))
+    finally:
+        del sys.modules["dataset"]
+    got = codes.code_row_bytes(top, bottom, "cls/img_0.png")
+    assert got == want and "dataset" not in sys.modules
+    path = str(tmp_path / "codes.db")
+    with codes.CodeStore(path, "w", backend="sqlite") as st:
+        codes.write_code_rows(st, [top, top + 1], [bottom, bottom + 1], ["a/0.png", "a/1.png"], start=0)
+        codes.write_code_rows(st, [top + 2], [bottom + 2], ["b/2.png"], start=2)
+        st.put(b"length", b"3")
+    ds = codes.CodeDataset(path)
+    assert len(ds) == 3
+    t2, b2, name = ds[2]
+    assert name == "b/2.png" and torch.equal(t2, torch.from_numpy(top + 2)) and torch.equal(b2, torch.from_numpy(bottom + 2))
+    with codes.CodeStore(path, "r") as st:
+        assert st.get(b"1") == codes.code_row_bytes(top + 1, bottom + 1, "a/1.png") and st.get(b"length") == b"3"
+
+
+def test_launch_spawns_ranks_and_joins_the_group(amd, tmp_path):
+    """distributed.launch (launch.py:22-49) with the gloo backend: two child ranks, environment-first bring-up."""
+    out = str(tmp_path / "ranks")
+    os.makedirs(out)
+    amd.distributed.launch(_launch_probe, 2, 1, 0, "auto", args=(out,), backend="gloo")
+    assert sorted(os.listdir(out)) == ["0_of_2_local0", "1_of_2_local1"]
+
+
+def _launch_probe(out):
+    import vqvae2_amd.distributed as d
+    x = torch.ones(2) * (d.get_rank() + 1)
+    d.all_reduce(x)
+    assert float(x[0]) == 3.0
+    open(os.path.join(out, f"{d.get_rank()}_of_{d.get_world_size()}_local{d.get_local_rank()}"), "w").close()
+    d.synchronize()
 
 
 def test_distributed_helpers_single_process(amd):

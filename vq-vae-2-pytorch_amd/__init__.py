@@ -6,5 +6,6 @@ Public surface mirrors /root/reference/vqvae.py and distributed/__init__.py:1-13
 from .vqvae import VQVAE, Quantize, ResBlock, Encoder, Decoder, Conv2d, ConvTranspose2d, ReLU  # noqa: F401
 from . import distributed  # noqa: F401
 from . import ops  # noqa: F401
+from . import codes  # noqa: F401
 from .optim import FusedAdam, CycleScheduler  # noqa: F401
 from .train import Stage1Trainer, stage1_loss  # noqa: F401

@@ -64,7 +64,9 @@ def _load():
         "vq2_slice_copy": (C.c_int, [P, I32, P, I32, I64, I32, C.c_int, P]),
         "vq2_vq_prepare": (C.c_int, [P, P, P, I32, I32, P]),
         "vq2_vq_fwd_workspace_floats": (SZ, [I64]),
-        "vq2_vq_fwd": (C.c_int, [P, I32, P, P, P, I64, I32, I32, P, P, I32, P, P, P, P]),
+        "vq2_vq_fwd": (C.c_int, [P, I32, P, P, P, I64, I32, I32, P, P, I32, P, P]),
+        "vq2_vq_stats_workspace_bytes": (SZ, [I64, I32, I32]),
+        "vq2_vq_stats": (C.c_int, [P, I32, P, I64, I32, I32, P, P, P, SZ, P]),
         "vq2_vq_loss": (C.c_int, [P, I64, I32, P, P]),
         "vq2_vq_bwd": (C.c_int, [P, I32, P, P, I32, P, P, I64, I32, I32, P, I32, P]),
         "vq2_vq_ema_update": (C.c_int, [P, P, P, P, P, I32, I32, D, D, P, P]),

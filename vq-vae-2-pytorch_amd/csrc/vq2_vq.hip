@@ -30,15 +30,13 @@ __global__ __launch_bounds__(64 * NW) void vq_fwd_kernel(const float *__restrict
                                                      const float *__restrict__ enorm,   // [K]
                                                      int64_t M, int D, int K, int64_t *__restrict__ idx_out,
                                                      float *__restrict__ out, int ldo,
-                                                     float *__restrict__ loss_partial, float *__restrict__ counts,
-                                                     float *__restrict__ sumsT) {
+                                                     float *__restrict__ loss_partial) {
     constexpr int HS = DP / 2;  // MFMA k-steps; lane half h covers d in [h*HS, (h+1)*HS)
     constexpr int NT = 64 * NW, ROWS = 32 * NW;
     extern __shared__ __attribute__((aligned(16))) float vq_smem[];
-    float *Es = vq_smem;                                   // [DP][VQ_CT]; later [ROWS slots][DP]
-    float *En = vq_smem + DP * VQ_CT;                      // [max(VQ_CT, ROWS)]; later slot codes
-    float *wsum = En + (VQ_CT > ROWS ? VQ_CT : ROWS);      // [NW]
-    int *slead = reinterpret_cast<int *>(wsum + NW);       // [ROWS]
+    float *Es = vq_smem;                                   // [DP][VQ_CT]
+    float *En = vq_smem + DP * VQ_CT;                      // [VQ_CT]
+    float *wsum = En + VQ_CT;                              // [NW]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, h = lane >> 5;
@@ -134,83 +132,241 @@ __global__ __launch_bounds__(64 * NW) void vq_fwd_kernel(const float *__restrict
     __syncthreads();
     if (tid < NW / 4 && loss_partial && (int64_t)(blockIdx.x * (NW / 4) + tid) * VQ_ROWS < M)   // one partial per 128 vectors
         loss_partial[blockIdx.x * (NW / 4) + tid] = (wsum[4 * tid] + wsum[4 * tid + 1]) + (wsum[4 * tid + 2] + wsum[4 * tid + 3]);
+}
 
-    // EMA statistics (vqvae.py:55-56): sumsT[code][:] += x rows.  Early in training (and on synthetic
-    // data) most vectors pick the same few codes, and same-address float atomics serialise at the
-    // memory side (~25 ns each), so equal codes are merged on chip first: per wave in registers, then
-    // per workgroup in LDS (the staging buffer is free now); one 4*D-byte atomic burst per distinct
-    // code leaves the workgroup.
-    if (sumsT) {
-        __syncthreads();                                 // every wave is done with Es / En
-        float *ssum = Es;                                // [ROWS slots][DP]
-        int *scode = reinterpret_cast<int *>(En);        // [ROWS] code of a slot, -1 = unused
-        // The wave's 32 vectors go from registers to its own 32 x DP corner of the (now free) staging buffer, so
-        // that the per-code sums below read rows with ~64-cycle LDS loads instead of dependent L2 round trips
-        // (16-byte groups XOR-swizzled by the row: conflict-free both ways).  Slot i later overwrites row i of
-        // the same corner: by then every row <= i has been consumed (leaders are taken in increasing order).
-        float *xt = Es + wave * 32 * DP;
-        constexpr int GM = DP / 4 - 1;
-#pragma unroll
-        for (int s = 0; s < HS; s += 4)
-            *reinterpret_cast<float4 *>(xt + col * DP + ((((h * HS + s) >> 2) ^ (col & GM)) << 2)) =
-                make_float4(xf[s], xf[s + 1], xf[s + 2], xf[s + 3]);
-        const int lg = lane >> 2, lq = lane & 3;         // this lane's 16-byte group / element when it reads column `lane`
-        unsigned long long rem = __ballot(rv && h == 0);
-        int nslots = 0;
-        while (rem) {
-            const int leader = __ffsll((long long)rem) - 1;
-            const int code = __shfl(besti, leader, 64);
-            const unsigned long long same = __ballot(rv && h == 0 && besti == code);
-            float v = 0.f;
-            unsigned long long it = same;
-            while (it) {
-                const int r = __ffsll((long long)it) - 1;
-                it &= it - 1;
-                if (lane < DP) v += xt[r * DP + (((lg ^ (r & GM)) << 2) | lq)];
-            }
-            const int slot = wave * 32 + nslots;
-            if (lane < D) ssum[slot * DP + lane] = v;
-            if (lane == 0) scode[slot] = code;
-            ++nslots;
-            rem &= ~same;
+// ----------------------------------------------------------------------------------------------------------------
+// EMA statistics (vqvae.py:55-56): counts[k] = #{m : idx[m] == k}, sumsT[k][:] = sum of the rows x[m][:] with idx[m] == k.
+// Bit-reproducible by construction (no float atomics): a STABLE counting sort of the row numbers by code, then every
+// code's rows are summed in increasing row order along a fixed two-level tree (64 sorted positions per chunk, chunk
+// partials folded in chunk order).  The cost does not depend on how many codes are in use: the rows are gathered once
+// (M*D*4 bytes at the HBM/Infinity-Cache rate) whether all vectors pick one code or every code is used.
+//   hist   per block of ST_RB rows: LDS histogram (integer atomics: exact)             -> blockhist[b][k]
+//   scan   per code: exclusive prefix over the blocks, totals                          -> blockhist (in place), ncode, counts
+//   place  per block: codeoff = exclusive scan of ncode; stable local ranks            -> perm[pos] = row, scode[pos] = code
+//   chunk  per 64 sorted positions (one wave): runs of equal code summed in order      -> sumsT (complete runs) / carry
+//   fix    per code (one wave): zero for unused codes, carries folded in chunk order   -> sumsT
+constexpr int ST_RB = 1024;   // rows per sort block (= threads of hist / place)
+constexpr int ST_CH = 64;     // sorted positions per chunk (= one wave)
+
+__global__ __launch_bounds__(ST_RB) void vq_stats_hist_kernel(const int64_t *__restrict__ idx, int64_t M, int K,
+                                                              int *__restrict__ blockhist) {
+    extern __shared__ int st_hist[];
+    for (int k = threadIdx.x; k < K; k += ST_RB) st_hist[k] = 0;
+    __syncthreads();
+    const int64_t m = (int64_t)blockIdx.x * ST_RB + threadIdx.x;
+    if (m < M) {
+        int c = (int)idx[m];
+        c = c < 0 ? 0 : (c >= K ? K - 1 : c);
+        atomicAdd(&st_hist[c], 1);
+    }
+    __syncthreads();
+    int *dst = blockhist + (size_t)blockIdx.x * K;
+    for (int k = threadIdx.x; k < K; k += ST_RB) dst[k] = st_hist[k];
+}
+
+// 16 codes x 16 groups of blocks per workgroup: blockhist[b][k] becomes the number of rows with code k in blocks < b
+__global__ __launch_bounds__(256) void vq_stats_scan_kernel(int *__restrict__ blockhist, int NB, int K,
+                                                            int *__restrict__ ncode, float *__restrict__ counts) {
+    __shared__ int part[16][17];
+    const int kq = threadIdx.x & 15, bq = threadIdx.x >> 4;
+    const int k = blockIdx.x * 16 + kq;
+    const int per = (NB + 15) / 16;
+    const int b0 = bq * per, b1 = (b0 + per < NB) ? b0 + per : NB;
+    int sum = 0;
+    if (k < K)
+        for (int b = b0; b < b1; ++b) sum += blockhist[(size_t)b * K + k];
+    part[bq][kq] = sum;
+    __syncthreads();
+    int base = 0;
+    for (int q = 0; q < bq; ++q) base += part[q][kq];
+    if (k < K) {
+        int run = base;
+        for (int b = b0; b < b1; ++b) {
+            const int c = blockhist[(size_t)b * K + k];
+            blockhist[(size_t)b * K + k] = run;
+            run += c;
         }
-        if (lane >= nslots && lane < 32) scode[wave * 32 + lane] = -1;
-        __syncthreads();
-        if (tid < ROWS) {                                // leader of a code = its first slot in the workgroup
-            const int myc = scode[tid];
-            int lead = tid;
-            if (myc >= 0)
-                for (int q = 0; q < tid; ++q)
-                    if (scode[q] == myc) { lead = q; break; }
-            slead[tid] = lead;
-        }
-        __syncthreads();
-        for (int sl = wave; sl < ROWS; sl += NW) {       // fold followers into their leader (LDS atomics)
-            const int l = slead[sl];
-            if (scode[sl] >= 0 && l != sl && lane < D) atomicAdd(&ssum[l * DP + lane], ssum[sl * DP + lane]);
-        }
-        __syncthreads();
-        for (int sl = wave; sl < ROWS; sl += NW) {
-            const int c = scode[sl];
-            if (c >= 0 && slead[sl] == sl && lane < D) atomicAdd(sumsT + (size_t)c * D + lane, ssum[sl * DP + lane]);
+        if (bq == 15) {
+            ncode[k] = base + sum;
+            counts[k] = (float)(base + sum);   // exact: integers below 2^24 (M <= 16.7M rows per call)
         }
     }
 }
 
-// counts[k] += #{m : idx[m] == k}: LDS-privatised histogram, then one contiguous burst of atomics per
-// workgroup (integers are exact in fp32 up to 2^24, so the result does not depend on the order)
-__global__ __launch_bounds__(256) void vq_hist_kernel(const int64_t *__restrict__ idx, int64_t M, int K,
-                                                      float *__restrict__ counts) {
-    extern __shared__ int hist[];
-    for (int k = threadIdx.x; k < K; k += 256) hist[k] = 0;
-    __syncthreads();
-    for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
-        const int c = (int)idx[m];
-        if ((unsigned)c < (unsigned)K) atomicAdd(&hist[c], 1);
+__global__ __launch_bounds__(ST_RB) void vq_stats_place_kernel(const int64_t *__restrict__ idx, int64_t M, int K,
+                                                               const int *__restrict__ blockoff,
+                                                               const int *__restrict__ ncode, int *__restrict__ codeoff,
+                                                               int *__restrict__ perm, int *__restrict__ scode) {
+    extern __shared__ int st_cnt[];   // [K] next free position of a code for this block; then [16] wave totals
+    int *wtot = st_cnt + K;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    // codeoff = exclusive scan of ncode: KP consecutive codes per thread, wave scan, 16 wave totals
+    const int KP = (K + ST_RB - 1) / ST_RB;
+    const int k0 = tid * KP;
+    int local = 0;
+    for (int j = 0; j < KP; ++j)
+        if (k0 + j < K) local += ncode[k0 + j];
+    int incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
     }
+    if (lane == 63) wtot[wave] = incl;
     __syncthreads();
-    for (int k = threadIdx.x; k < K; k += 256)
-        if (hist[k]) atomicAdd(counts + k, (float)hist[k]);
+    int wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += wtot[w];
+    int run = wbase + incl - local;
+    const int *boff = blockoff + (size_t)b * K;
+    for (int j = 0; j < KP; ++j) {
+        const int k = k0 + j;
+        if (k < K) {
+            st_cnt[k] = run + boff[k];
+            if (b == 0) codeoff[k] = run;
+            run += ncode[k];
+        }
+    }
+    if (b == 0 && tid == ST_RB - 1) codeoff[K] = run;   // the last thread's running sum is the grand total
+    // stable rank inside the wave: lanes with equal codes, in lane (= row) order
+    const int64_t m = (int64_t)b * ST_RB + tid;
+    const bool valid = m < M;
+    int c = -1;
+    if (valid) {
+        c = (int)idx[m];
+        c = c < 0 ? 0 : (c >= K ? K - 1 : c);
+    }
+    int wrank = 0, wcount = 0;
+    bool islast = false;
+    unsigned long long rem = __ballot(valid);
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    while (rem) {
+        const int leader = __ffsll((long long)rem) - 1;
+        const int lc = __shfl(c, leader, 64);
+        const unsigned long long same = __ballot(valid && c == lc);
+        if (valid && c == lc) {
+            wrank = __popcll(same & below);
+            wcount = __popcll(same);
+            islast = (same >> lane) == 1ull;
+        }
+        rem &= ~same;
+    }
+    // the 16 waves take their turns in row order: base position of the code, then the code's counter moves on
+    int pos = 0;
+    for (int w = 0; w < ST_RB / 64; ++w) {
+        __syncthreads();
+        if (wave == w && valid) {
+            const int basep = st_cnt[c];
+            pos = basep + wrank;
+            if (islast) st_cnt[c] = basep + wcount;
+        }
+    }
+    if (valid) {
+        perm[pos] = (int)m;
+        scode[pos] = c;
+    }
+}
+
+template <int NV>   // floats per lane: D <= 64 * NV
+__global__ __launch_bounds__(256) void vq_stats_chunk_kernel(const float *__restrict__ x, int ldx, int D, int64_t M,
+                                                             const int *__restrict__ perm, const int *__restrict__ scode,
+                                                             const int *__restrict__ codeoff, float *__restrict__ sumsT,
+                                                             float *__restrict__ carry) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t g = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t p0 = g * ST_CH;
+    if (p0 >= M) return;
+    const int n = (M - p0 < ST_CH) ? (int)(M - p0) : ST_CH;
+    const int row_l = (lane < n) ? perm[p0 + lane] : 0;
+    const int code_l = (lane < n) ? scode[p0 + lane] : -1;
+    float acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+    int cur = __builtin_amdgcn_readlane(code_l, 0);
+    auto flush = [&](int k) {
+        const int s = codeoff[k], e = codeoff[k + 1];
+        float *dst;
+        if ((int64_t)s >= p0 && (int64_t)e <= p0 + ST_CH) dst = sumsT + (size_t)k * D;             // the code's whole segment
+        else dst = carry + ((size_t)g * 2 + ((int64_t)s <= p0 ? 0 : 1)) * D;                      // head / tail partial
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lane + 64 * i < D) dst[lane + 64 * i] = acc[i];
+    };
+    constexpr int U = 16;   // rows in flight per wave
+    for (int r0 = 0; r0 < n; r0 += U) {
+        float v[U][NV];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int r = (r0 + j < n) ? r0 + j : n - 1;
+            const int row = __builtin_amdgcn_readlane(row_l, r);
+            const float *src = x + (size_t)row * ldx;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v[j][i] = (lane + 64 * i < D) ? src[lane + 64 * i] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            if (r0 + j < n) {                                    // wave-uniform
+                const int code = __builtin_amdgcn_readlane(code_l, r0 + j);
+                if (code != cur) {
+                    flush(cur);
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+                    cur = code;
+                }
+#pragma unroll
+                for (int i = 0; i < NV; ++i) acc[i] += v[j][i];
+            }
+        }
+    }
+    flush(cur);
+}
+
+// One workgroup per code.  A code whose rows span n > 1 chunks has one partial per chunk; a single chain over them would
+// be a latency chain of n dependent L2 round trips (n = 2,048 when every vector of a 32 x 64 x 64 batch picks the same
+// code), so the fold is a fixed two-stage tree instead: CL = 256 / (D/4) interleaved chains (thread (c, q) adds the
+// float4 q of chunks g0 + c, g0 + c + CL, ... in order, 8 loads in flight), then the CL chain sums in order of c.
+__global__ __launch_bounds__(256) void vq_stats_fix_kernel(int K, int D, const int *__restrict__ codeoff,
+                                                           const float *__restrict__ carry, float *__restrict__ sumsT) {
+    __shared__ float4 red[256];
+    const int k = blockIdx.x;
+    const int s = codeoff[k], e = codeoff[k + 1];
+    const int Q = D >> 2, CL = 256 / Q;
+    const int q = threadIdx.x % Q, c = threadIdx.x / Q;
+    float4 *dst = reinterpret_cast<float4 *>(sumsT + (size_t)k * D);
+    if (e == s) {
+        if (c == 0) dst[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const int g0 = s / ST_CH, g1 = (e - 1) / ST_CH;
+    if (g0 == g1) return;   // the chunk kernel wrote the complete sum
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int U = 8;
+    for (int gb = g0 + c; gb <= g1; gb += CL * U) {
+        float4 v[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int g = gb + j * CL;
+            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g <= g1)
+                v[j] = *reinterpret_cast<const float4 *>(carry + ((size_t)g * 2 + (s <= g * ST_CH ? 0 : 1)) * D + 4 * q);
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {   // adding the zero of a slot past g1 changes nothing (x + 0 = x, and -0 + 0 = +0 only
+            acc.x += v[j].x;            // where the true sum is a zero as well)
+            acc.y += v[j].y;
+            acc.z += v[j].z;
+            acc.w += v[j].w;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (c == 0) {
+        float4 t = red[q];
+        for (int cc = 1; cc < CL; ++cc) {
+            const float4 o = red[cc * Q + q];
+            t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+        }
+        dst[q] = t;
+    }
 }
 
 // embedT[k][d] = embed[d][k], enorm[k] = sum_d embed[d][k]^2: 64 codes x 4 d-lanes per workgroup
@@ -342,40 +498,97 @@ extern "C" size_t vq2_vq_fwd_workspace_floats(int64_t M) { return M <= 0 ? 0 : (
 
 extern "C" int vq2_vq_fwd(const float *x, int32_t ldx, const float *embed, const float *embedT, const float *enorm,
                           int64_t M, int32_t D, int32_t K, int64_t *idx, float *out, int32_t ldo, float *loss_partial,
-                          float *counts, float *sumsT, vq2_stream_t stream) {
+                          vq2_stream_t stream) {
     VQ2_REQUIRE(x && embed && embedT && enorm && idx, "vq_fwd: null pointer");
     VQ2_REQUIRE(M > 0 && K > 0 && K % 4 == 0 && (D == 4 || D == 8 || D == 16 || D == 32 || D == 64),
                 "vq_fwd: need D in {4,8,16,32,64} and K %% 4 == 0 (D=%d K=%d)", D, K);
     VQ2_REQUIRE(ldx >= D && ldx % 4 == 0 && (!out || (ldo >= D && ldo % 4 == 0)), "vq_fwd: bad pixel strides");
     VQ2_REQUIRE(aligned16(x) && aligned16(embed) && aligned16(embedT) && (!out || aligned16(out)),
                 "vq_fwd: pointers must be 16-byte aligned");
-    VQ2_REQUIRE((counts == nullptr) == (sumsT == nullptr), "vq_fwd: counts and sumsT go together");
     hipStream_t s = to_stream(stream);
-    ProfScope prof("vq_fwd", 2.0 * (double)M * D * K, 4.0 * ((double)M * D * 2 + (double)D * K), s);
+    ProfScope prof(prof_label("vq_fwd|M=%lld,D=%d,K=%d", (long long)M, D, K), 2.0 * (double)M * D * K,
+                   4.0 * ((double)M * D * 2 + (double)D * K), s);
     const bool big = M >= 512 * 256;   // 512-vector workgroups still cover every CU
 #define VQ2_LAUNCH_VQ(DP, NW, CT)                                                                                    \
     do {                                                                                                             \
-        const size_t lds = ((size_t)DP * CT + (CT > 32 * NW ? CT : 32 * NW) + NW + 32 * NW) * sizeof(float);         \
+        const size_t lds = ((size_t)DP * CT + CT + NW) * sizeof(float);                                              \
         const unsigned grid = (unsigned)((M + 32 * NW - 1) / (32 * NW));                                             \
         allow_big_lds(vq_fwd_kernel<DP, NW, CT>, lds);                                                               \
         hipLaunchKernelGGL((vq_fwd_kernel<DP, NW, CT>), dim3(grid), dim3(64 * NW), lds, s, x, ldx, embed, embedT, enorm, M, \
-                           D, K, idx, out, ldo, loss_partial, counts, sumsT);                                        \
+                           D, K, idx, out, ldo, loss_partial);                                                       \
     } while (0)
     if (D <= 16) { if (big) VQ2_LAUNCH_VQ(16, 16, 512); else VQ2_LAUNCH_VQ(16, 4, 128); }
     else if (D <= 32) { if (big) VQ2_LAUNCH_VQ(32, 16, 512); else VQ2_LAUNCH_VQ(32, 4, 128); }
     else { if (big) VQ2_LAUNCH_VQ(64, 16, 512); else VQ2_LAUNCH_VQ(64, 4, 128); }
 #undef VQ2_LAUNCH_VQ
-    if (int e = check_launch("vq_fwd_kernel")) return e;
-    if (counts) {
-        VQ2_REQUIRE(K <= 16384, "vq_fwd: n_embed > 16384 not supported by the histogram kernel");
-        // same-bin LDS atomics of a wave serialise (collapsed codebooks: all 64 lanes on one bin), so the
-        // histogram wants many short workgroups, not few long ones: 4-8 indices per thread
-        const int hb = (int)((M + 256 * 4 - 1) / (256 * 4));
-        hipLaunchKernelGGL(vq_hist_kernel, dim3(hb < 1 ? 1 : (hb > 256 ? 256 : hb)), dim3(256), (size_t)K * sizeof(int), s,
-                           idx, M, K, counts);
-        return check_launch("vq_hist_kernel");
-    }
-    return VQ2_OK;
+    return check_launch("vq_fwd_kernel");
+}
+
+namespace {
+struct StatsLayout {
+    size_t blockhist, ncode, codeoff, perm, scode, carry, total;
+    int NB;
+    int64_t NCH;
+};
+inline size_t up16(size_t b) { return (b + 15) / 16 * 16; }
+inline StatsLayout stats_layout(int64_t M, int32_t D, int32_t K) {
+    StatsLayout L;
+    L.NB = (int)((M + ST_RB - 1) / ST_RB);
+    L.NCH = (M + ST_CH - 1) / ST_CH;
+    size_t o = 0;
+    L.blockhist = o; o += up16((size_t)L.NB * K * sizeof(int));
+    L.ncode = o;     o += up16((size_t)K * sizeof(int));
+    L.codeoff = o;   o += up16((size_t)(K + 1) * sizeof(int));
+    L.perm = o;      o += up16((size_t)M * sizeof(int));
+    L.scode = o;     o += up16((size_t)M * sizeof(int));
+    L.carry = o;     o += up16((size_t)L.NCH * 2 * D * sizeof(float));
+    L.total = o;
+    return L;
+}
+}  // namespace
+
+extern "C" size_t vq2_vq_stats_workspace_bytes(int64_t M, int32_t D, int32_t K) {
+    if (M <= 0 || D <= 0 || K <= 0) return 0;
+    return stats_layout(M, D, K).total;
+}
+
+extern "C" int vq2_vq_stats(const float *x, int32_t ldx, const int64_t *idx, int64_t M, int32_t D, int32_t K,
+                            float *counts, float *sumsT, void *ws, size_t ws_bytes, vq2_stream_t stream) {
+    VQ2_REQUIRE(x && idx && counts && sumsT && ws, "vq_stats: null pointer");
+    VQ2_REQUIRE(M > 0 && M < (1ll << 24) && D >= 4 && D <= 256 && (D & (D - 1)) == 0 && K > 0 && K <= 16384 && ldx >= D,
+                "vq_stats: need 0 < M < 2^24, D a power of two in 4..256, K <= 16384 (M=%lld D=%d K=%d)", (long long)M, D, K);
+    VQ2_REQUIRE(aligned16(sumsT), "vq_stats: sumsT must be 16-byte aligned");
+    const StatsLayout L = stats_layout(M, D, K);
+    if (ws_bytes < L.total) return set_error(VQ2_ERR_WORKSPACE, "vq_stats: workspace %zu < %zu bytes", ws_bytes, L.total);
+    VQ2_REQUIRE(aligned16(ws), "vq_stats: workspace must be 16-byte aligned");
+    hipStream_t s = to_stream(stream);
+    char *base = static_cast<char *>(ws);
+    int *blockhist = reinterpret_cast<int *>(base + L.blockhist), *ncode = reinterpret_cast<int *>(base + L.ncode);
+    int *codeoff = reinterpret_cast<int *>(base + L.codeoff), *perm = reinterpret_cast<int *>(base + L.perm);
+    int *scode = reinterpret_cast<int *>(base + L.scode);
+    float *carry = reinterpret_cast<float *>(base + L.carry);
+    ProfScope prof(prof_label("vq_stats|M=%lld,D=%d,K=%d", (long long)M, D, K), (double)M * D,
+                   4.0 * ((double)M * D + (double)K * D) + 8.0 * M, s);
+    const size_t lds_h = (size_t)K * sizeof(int), lds_p = ((size_t)K + 16) * sizeof(int);
+    allow_big_lds(vq_stats_hist_kernel, lds_h);
+    hipLaunchKernelGGL(vq_stats_hist_kernel, dim3(L.NB), dim3(ST_RB), lds_h, s, idx, M, K, blockhist);
+    if (int e = check_launch("vq_stats_hist_kernel")) return e;
+    hipLaunchKernelGGL(vq_stats_scan_kernel, dim3((K + 15) / 16), dim3(256), 0, s, blockhist, L.NB, K, ncode, counts);
+    if (int e = check_launch("vq_stats_scan_kernel")) return e;
+    allow_big_lds(vq_stats_place_kernel, lds_p);
+    hipLaunchKernelGGL(vq_stats_place_kernel, dim3(L.NB), dim3(ST_RB), lds_p, s, idx, M, K, blockhist, ncode, codeoff,
+                       perm, scode);
+    if (int e = check_launch("vq_stats_place_kernel")) return e;
+    const unsigned cgrid = (unsigned)((L.NCH + 3) / 4);
+    if (D <= 64)
+        hipLaunchKernelGGL(vq_stats_chunk_kernel<1>, dim3(cgrid), dim3(256), 0, s, x, ldx, D, M, perm, scode, codeoff, sumsT, carry);
+    else if (D <= 128)
+        hipLaunchKernelGGL(vq_stats_chunk_kernel<2>, dim3(cgrid), dim3(256), 0, s, x, ldx, D, M, perm, scode, codeoff, sumsT, carry);
+    else
+        hipLaunchKernelGGL(vq_stats_chunk_kernel<4>, dim3(cgrid), dim3(256), 0, s, x, ldx, D, M, perm, scode, codeoff, sumsT, carry);
+    if (int e = check_launch("vq_stats_chunk_kernel")) return e;
+    hipLaunchKernelGGL(vq_stats_fix_kernel, dim3(K), dim3(256), 0, s, K, D, codeoff, carry, sumsT);
+    return check_launch("vq_stats_fix_kernel");
 }
 
 extern "C" int vq2_vq_loss(const float *loss_partial, int64_t M, int32_t D, float *diff, vq2_stream_t stream) {

@@ -1,142 +1,163 @@
-"""Mirror of the reference's distributed/ package (distributed/__init__.py:1-13) on RCCL.
+"""The reference's `distributed` package surface (/root/reference/distributed/__init__.py:1-13) on RCCL.
 
-Same names and argument meaning as /root/reference/distributed/distributed.py and launch.py.
-On ROCm the torch.distributed backend string "nccl" IS RCCL; one process per GPU.
+Same eleven public names with the same argument meaning: get_rank, get_local_rank, is_primary, synchronize,
+get_world_size, all_reduce, all_gather, reduce_dict, data_sampler, LOCAL_PROCESS_GROUP, launch.  On ROCm the
+torch.distributed backend string "nccl" IS RCCL; one process per GPU.
+
+Bring-up is environment-first: a process started by `python -m torch.distributed.run` (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_ADDR / MASTER_PORT) calls bringup() -- or launch(), which notices the environment -- and gets
+device binding + the RCCL group in one place.  launch() without such an environment starts the per-GPU processes
+itself (the reference's behaviour, distributed/launch.py:22-49) by exporting the same variables to each child
+and sending it through the same bringup().
 """
 import os
 import socket
 
 import torch
 from torch import distributed as dist
-from torch import multiprocessing as mp
-from torch.utils import data
 
-LOCAL_PROCESS_GROUP = None
+LOCAL_PROCESS_GROUP = None   # kept for name parity (launch.py:85-90); get_local_rank() reads LOCAL_RANK first
+
+_ENV_KEYS = ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")
+
+
+def _group_up():
+    return dist.is_available() and dist.is_initialized()
+
+
+def get_rank():
+    return dist.get_rank() if _group_up() else 0
+
+
+def get_world_size():
+    return dist.get_world_size() if _group_up() else 1
 
 
 def is_primary():
     return get_rank() == 0
 
 
-def get_rank():
-    if not dist.is_available() or not dist.is_initialized():
-        return 0
-    return dist.get_rank()
-
-
 def get_local_rank():
-    if not dist.is_available() or not dist.is_initialized():
+    if not _group_up():
         return 0
+    if "LOCAL_RANK" in os.environ:
+        return int(os.environ["LOCAL_RANK"])
     if LOCAL_PROCESS_GROUP is None:
-        # torchrun-style launches carry the local rank in the environment
-        if "LOCAL_RANK" in os.environ:
-            return int(os.environ["LOCAL_RANK"])
-        raise ValueError("tensorfn.distributed.LOCAL_PROCESS_GROUP is None")  # distributed.py:33-34
+        raise ValueError("no LOCAL_RANK in the environment and no LOCAL_PROCESS_GROUP")   # distributed.py:33-34
     return dist.get_rank(group=LOCAL_PROCESS_GROUP)
 
 
 def synchronize():
-    if not dist.is_available() or not dist.is_initialized():
-        return
-    if dist.get_world_size() == 1:
-        return
-    dist.barrier()
-
-
-def get_world_size():
-    if not dist.is_available() or not dist.is_initialized():
-        return 1
-    return dist.get_world_size()
+    if get_world_size() > 1:
+        dist.barrier()
 
 
 def all_reduce(tensor, op=dist.ReduceOp.SUM):
-    """distributed.py:64-72: identity at world size 1, else in-place all-reduce; returns tensor."""
-    if get_world_size() == 1:
-        return tensor
-    dist.all_reduce(tensor, op=op)
+    """distributed.py:64-72: identity at world size 1, else in-place all-reduce; returns the tensor."""
+    if get_world_size() > 1:
+        dist.all_reduce(tensor, op=op)
     return tensor
 
 
 def all_gather(data):
-    """distributed.py:75-107: gather arbitrary picklable objects from every rank into a list."""
-    world_size = get_world_size()
-    if world_size == 1:
+    """distributed.py:75-107: one picklable object per rank -> list ordered by rank."""
+    world = get_world_size()
+    if world == 1:
         return [data]
-    out = [None] * world_size
-    dist.all_gather_object(out, data)
-    return out
+    gathered = [None] * world
+    dist.all_gather_object(gathered, data)
+    return gathered
 
 
 def reduce_dict(input_dict, average=True):
-    """distributed.py:110-132: reduce a dict of 0-dim tensors to rank 0 (averaged by default)."""
-    world_size = get_world_size()
-    if world_size < 2:
+    """distributed.py:110-132: dict of same-shaped tensors summed onto rank 0 (mean if `average`)."""
+    world = get_world_size()
+    if world < 2:
         return input_dict
+    names = sorted(input_dict)
     with torch.no_grad():
-        keys = sorted(input_dict.keys())
-        values = torch.stack([input_dict[k] for k in keys], 0)
-        dist.reduce(values, dst=0)
-        if dist.get_rank() == 0 and average:
-            values /= world_size
-        return {k: v for k, v in zip(keys, values)}
+        stacked = torch.stack([input_dict[n] for n in names])
+        dist.reduce(stacked, dst=0)
+        if average and dist.get_rank() == 0:
+            stacked /= world
+    return dict(zip(names, stacked))
 
 
 def data_sampler(dataset, shuffle, distributed):
+    """distributed.py:135-143."""
+    from torch.utils import data
     if distributed:
         return data.distributed.DistributedSampler(dataset, shuffle=shuffle)
-    if shuffle:
-        return data.RandomSampler(dataset)
-    return data.SequentialSampler(dataset)
+    return data.RandomSampler(dataset) if shuffle else data.SequentialSampler(dataset)
 
 
-# ------------------------------------------------------------------ launch.py:10-92
-def find_free_port():
-    sock = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-    sock.bind(("", 0))
-    port = sock.getsockname()[1]
-    sock.close()
-    return port
-
-
-def launch(fn, n_gpu_per_machine, n_machine=1, machine_rank=0, dist_url=None, args=()):
-    world_size = n_machine * n_gpu_per_machine
-    if world_size > 1:
-        if "OMP_NUM_THREADS" not in os.environ:
-            os.environ["OMP_NUM_THREADS"] = "1"
-        if dist_url == "auto":
-            if n_machine != 1:
-                raise ValueError('dist_url="auto" not supported in multi-machine jobs')
-            dist_url = f"tcp://127.0.0.1:{find_free_port()}"
-        mp.spawn(distributed_worker, nprocs=n_gpu_per_machine,
-                 args=(fn, world_size, n_gpu_per_machine, machine_rank, dist_url, args), daemon=False)
-    else:
-        fn(*args)
-
-
-def distributed_worker(local_rank, fn, world_size, n_gpu_per_machine, machine_rank, dist_url, args,
-                       backend="nccl"):
-    if backend == "nccl" and not torch.cuda.is_available():
-        raise OSError("CUDA is not available. Please check your environments")  # launch.py:55-56
-    global_rank = machine_rank * n_gpu_per_machine + local_rank
-    # keep dmabuf IPC for RCCL on this driver
+# ---------------------------------------------------------------------------------------------- bring-up
+def bringup(backend="nccl"):
+    """Join the job described by the launcher environment: bind this process to its GPU, then create the process
+    group (RCCL for "nccl").  Returns (rank, local_rank, world_size).  A no-op at WORLD_SIZE 1 unless
+    VQ2_DP_FORCE=1 asks for a one-rank group (used to exercise the RCCL path on a single GPU)."""
+    # dmabuf IPC is the only mode the host driver supports; must be set before the HIP runtime starts
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    try:
-        dist.init_process_group(backend=backend, init_method=dist_url, world_size=world_size, rank=global_rank)
-    except Exception:
-        raise OSError("failed to initialize NCCL groups")  # launch.py:68-69
-    synchronize()
-    if backend == "nccl":
-        if n_gpu_per_machine > torch.cuda.device_count():
-            raise ValueError(f"specified n_gpu_per_machine larger than available device "
-                             f"({torch.cuda.device_count()})")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    gpu = backend == "nccl"
+    if gpu:
+        if not torch.cuda.is_available():
+            raise OSError("CUDA is not available. Please check your environments")   # launch.py:55-56
+        if local_rank >= torch.cuda.device_count():
+            raise ValueError(f"local rank {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible")
         torch.cuda.set_device(local_rank)
-    global LOCAL_PROCESS_GROUP
-    if LOCAL_PROCESS_GROUP is not None:
-        raise ValueError("torch.distributed.LOCAL_PROCESS_GROUP is not None")
-    n_machine = world_size // n_gpu_per_machine
-    for i in range(n_machine):
-        ranks_on_i = list(range(i * n_gpu_per_machine, (i + 1) * n_gpu_per_machine))
-        pg = dist.new_group(ranks_on_i)
-        if i == machine_rank:
-            LOCAL_PROCESS_GROUP = pg
-    fn(*args)
+    force = os.environ.get("VQ2_DP_FORCE", "0") != "0"
+    if (world > 1 or force) and not _group_up():
+        missing = [k for k in _ENV_KEYS if k not in os.environ]
+        if missing:
+            raise OSError(f"failed to initialize NCCL groups: {missing} not set")          # launch.py:68-69
+        kw = {"device_id": torch.device("cuda", local_rank)} if gpu else {}
+        try:
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        except Exception as exc:
+            raise OSError("failed to initialize NCCL groups") from exc
+        synchronize()
+    return rank, local_rank, world
+
+
+def find_free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def _child(local_rank, fn, world, per_machine, machine_rank, addr, port, backend, args):
+    os.environ.update(RANK=str(machine_rank * per_machine + local_rank), LOCAL_RANK=str(local_rank),
+                      WORLD_SIZE=str(world), MASTER_ADDR=addr, MASTER_PORT=str(port))
+    bringup(backend)
+    try:
+        fn(*args)
+    finally:
+        if _group_up():
+            dist.destroy_process_group()
+
+
+def launch(fn, n_gpu_per_machine, n_machine=1, machine_rank=0, dist_url=None, args=(), backend="nccl"):
+    """launch.py:22-49: run fn(*args) on n_machine x n_gpu_per_machine ranks, one process per GPU.  Under torchrun
+    (the launcher already made the processes) it only joins the group; otherwise it spawns the local ranks."""
+    world = n_machine * n_gpu_per_machine
+    if all(k in os.environ for k in _ENV_KEYS) and int(os.environ["WORLD_SIZE"]) == world:
+        bringup(backend)
+        return fn(*args)
+    if world == 1:
+        return fn(*args)
+    os.environ.setdefault("OMP_NUM_THREADS", "1")                    # launch.py:26-27
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")         # inherited by the children, before their HIP init
+    if dist_url in (None, "auto"):
+        if n_machine != 1:
+            raise ValueError('dist_url="auto" not supported in multi-machine jobs')       # launch.py:30-33
+        addr, port = "127.0.0.1", find_free_port()
+    else:
+        if not dist_url.startswith("tcp://"):
+            raise ValueError(f"dist_url must look like tcp://host:port, got {dist_url!r}")
+        addr, _, port = dist_url[len("tcp://"):].rpartition(":")
+    import torch.multiprocessing as mp
+    mp.spawn(_child, nprocs=n_gpu_per_machine, daemon=False,
+             args=(fn, world, n_gpu_per_machine, machine_rank, addr, int(port), backend, args))

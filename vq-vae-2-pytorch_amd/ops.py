@@ -8,7 +8,6 @@ every FLOP and every byte moved on this path is a libvq2 kernel.
 from dataclasses import dataclass
 import ctypes as C
 import os
-import weakref
 
 import torch
 from torch.autograd import Function
@@ -21,9 +20,11 @@ VQ2_MASK_AFTER_RESIDUAL = 4
 PACK_FWD = 0
 PACK_DGRAD = 1
 
-# bumped by FusedAdam (it updates weights through raw pointers, which does not touch
-# tensor._version); part of the packed-weight cache key
-WEIGHT_EPOCH = [0]
+# There is NO process-global mutable state on the autograd path (SURVEY 8b threading row): the packed-weight
+# cache lives on each weight tensor (`_vq2_packs`), raw-pointer weight updates are tracked per parameter
+# (`_vq2_epoch`, see touch_weights), and the deferred weight-gradient reduction / side stream of a training step
+# belong to the StepContext its Stage1Trainer hangs on its own parameters (`_vq2_ctx`), so two trainers or
+# models can coexist in one process and back-propagate on different autograd threads.
 
 
 def _stream():
@@ -123,16 +124,22 @@ def _desc(spec, n, h, w, ldx, ldy):
     return d
 
 
-_pack_cache = {}
+def touch_weights(params):
+    """Tell the packed-weight caches that `params` were updated through raw pointers (vq2_adam_step), which
+    does not bump tensor._version."""
+    for p in params:
+        p._vq2_epoch = getattr(p, "_vq2_epoch", 0) + 1
+
+
+def _pack_version(spec, weight):
+    return (weight.data_ptr(), weight._version, getattr(weight, "_vq2_epoch", 0), spec)
 
 
 def packed_weight(spec, weight, which):
-    """Kernel-layout copy of a reference-layout weight, cached until the weight changes."""
-    key = (id(weight), which)
-    ver = (weight.data_ptr(), weight._version, WEIGHT_EPOCH[0], spec)
-    hit = _pack_cache.get(key)
-    if hit is not None and (len(hit) < 3 or hit[2]() is not weight):
-        hit = None  # id() of a dead tensor was recycled: never trust that entry
+    """Kernel-layout copy of a reference-layout weight, cached ON the weight until it changes."""
+    packs = weight.__dict__.setdefault("_vq2_packs", {})
+    ver = _pack_version(spec, weight)
+    hit = packs.get(which)
     if hit is not None and hit[0] == ver:
         return hit[1]
     _require_cuda(weight, "weight")
@@ -140,11 +147,11 @@ def packed_weight(spec, weight, which):
     if not wsrc.is_contiguous():
         wsrc = wsrc.contiguous()
     n = spec.ci * spec.co * spec.k * spec.k
-    buf = hit[1] if (hit is not None and hit[1].numel() == n) else torch.empty(n, device=weight.device,
-                                                                               dtype=torch.float32)
+    buf = hit[1] if (hit is not None and hit[1].numel() == n and hit[1].device == weight.device) else \
+        torch.empty(n, device=weight.device, dtype=torch.float32)
     d = _desc(spec, 1, max(spec.k, 2), max(spec.k, 2), spec.ci, spec.co)
     check(lib.vq2_pack_weight(C.byref(d), which, _p(wsrc), _p(buf), _stream()), "pack_weight")
-    _pack_cache[key] = (ver, buf, weakref.ref(weight))
+    packs[which] = (ver, buf)
     return buf
 
 
@@ -188,8 +195,7 @@ class PackPlan:
             raise RuntimeError("PackPlan: a parameter was re-allocated; rebuild the plan")
         check(lib.vq2_pack_weights_batched(_p(self.jobs_dev), self.njobs, self.total, _stream()), "pack_batched")
         for spec, weight, which, buf in self.entries:
-            _pack_cache[(id(weight), which)] = ((weight.data_ptr(), weight._version, WEIGHT_EPOCH[0], spec), buf,
-                                                weakref.ref(weight))
+            weight.__dict__.setdefault("_vq2_packs", {})[which] = (_pack_version(spec, weight), buf)
 
 
 def conv_forward(spec, x, weight, bias, flags=0, residual=None, out=None):
@@ -225,7 +231,7 @@ def conv_dgrad(spec, xshape, dy, weight, mask=None, residual=None, out=None, mas
 def _grad_slot(param):
     """ParamArena: the gradient of `param` lands directly in the flat gradient buffer."""
     slot = getattr(param, "_vq2_grad", None) if param is not None else None
-    if slot is not None:
+    if slot is not None and param.grad is None:   # a second backward (accumulation) must not overwrite the first
         return slot.view_as(slot)  # fresh tensor object so autograd can adopt it as .grad without a copy
     return None if param is None else torch.empty_like(param, memory_format=torch.contiguous_format)
 
@@ -241,7 +247,7 @@ class WgradBatch:
         self.tables = {}
         self.dirty = True
 
-    def launch(self, spec, x, dy, relu_in, weight, bias, want_db):
+    def launch(self, spec, x, dy, relu_in, weight, bias, want_db, side=None):
         n, h, w, _ = x.shape
         key = (id(weight), n, h, w, ld_of(x), ld_of(dy), relu_in)
         d = _desc(spec, n, h, w, ld_of(x), ld_of(dy))
@@ -256,8 +262,7 @@ class WgradBatch:
             ent = {"ws": ws, "nbytes": nbytes, "job": job, "dw": dw, "db": db, "used": False}
             self.entries[key] = ent
             self.dirty = True
-        side = WGRAD_STREAM[0]
-        if side is not None and n * h * w > WGRAD_STREAM_MAX_PIXELS[0]:
+        if side is not None and n * h * w > WGRAD_STREAM_MAX_PIXELS:
             side = None        # a launch that fills the chip by itself gains nothing from a second stream
         if side is not None:   # off the backward critical path: overlaps the next layers' data gradients
             side.wait_event(torch.cuda.current_stream().record_event())
@@ -320,14 +325,26 @@ class WgradBatch:
         self.order = []
 
 
-WGRAD_BATCH = [None]
+class StepContext:
+    """What one Stage1Trainer's backward pass shares between its layers: the deferred split-K reduction
+    (WgradBatch) and the optional side stream for weight gradients.  Hung on the trainer's own parameters as
+    `_vq2_ctx`; `active` only while that trainer's backward runs (a stand-alone .backward() on the same model
+    takes the immediate per-layer path).  Weight gradients are off the backward critical path (only the optimizer
+    consumes them), so on a side stream they overlap the next layers' data-gradient launches; only legal when
+    they land in arena slots that nobody reads before the trainer joins the streams."""
 
-# Stage1Trainer sets this to a side HIP stream: weight gradients are off the backward critical path
-# (only the optimizer consumes them), so they run concurrently with the next layers' data-gradient
-# launches and fill the SIMD slots those leave idle.  Only legal when the gradients land in arena
-# slots that nobody reads before the trainer joins the streams.
-WGRAD_STREAM = [None]
-WGRAD_STREAM_MAX_PIXELS = [int(os.environ.get("VQ2_WGRAD_STREAM_MAXPIX", str(1 << 62)))]
+    def __init__(self, wgrad_stream=None):
+        self.batch = WgradBatch()
+        self.stream = wgrad_stream
+        self.active = False
+
+
+def _step_ctx(weight):
+    ctx = getattr(weight, "_vq2_ctx", None)
+    return ctx if (ctx is not None and ctx.active) else None
+
+
+WGRAD_STREAM_MAX_PIXELS = int(os.environ.get("VQ2_WGRAD_STREAM_MAXPIX", str(1 << 62)))
 
 
 def conv_wgrad(spec, x, dy, relu_in, weight, bias=None, want_dw=True, want_db=True):
@@ -335,16 +352,16 @@ def conv_wgrad(spec, x, dy, relu_in, weight, bias=None, want_dw=True, want_db=Tr
     n, h, w, _ = x.shape
     d = _desc(spec, n, h, w, ld_of(x), ld_of(dy))
     nbytes = lib.vq2_conv_wgrad_workspace_bytes(C.byref(d))
-    batch = WGRAD_BATCH[0]
-    if batch is not None and getattr(weight, "_vq2_grad", None) is not None and \
-            (bias is None or getattr(bias, "_vq2_grad", None) is not None) and \
+    sc = _step_ctx(weight)
+    if sc is not None and getattr(weight, "_vq2_grad", None) is not None and weight.grad is None and \
+            (bias is None or (getattr(bias, "_vq2_grad", None) is not None and bias.grad is None)) and \
             (bias is None or bias.numel() == spec.cout):
-        dw, db = batch.launch(spec, x, dy, relu_in, weight, bias, want_db)
+        dw, db = sc.batch.launch(spec, x, dy, relu_in, weight, bias, want_db, sc.stream)
         return (dw if want_dw else None), db
     dw = _grad_slot(weight)
     db = _grad_slot(bias) if (bias is not None and want_db) else None
-    side = WGRAD_STREAM[0]
-    if side is not None and getattr(weight, "_vq2_grad", None) is not None:
+    side = sc.stream if sc is not None else None
+    if side is not None and getattr(weight, "_vq2_grad", None) is not None and dw.data_ptr() == weight._vq2_grad.data_ptr():
         side.wait_event(torch.cuda.current_stream().record_event())
         with torch.cuda.stream(side):
             ws = torch.empty(max(nbytes // 4, 4), device=x.device, dtype=torch.float32)
@@ -576,11 +593,12 @@ class ResBlockFn(Function):
             dx = torch.empty((n, h, w, c), device=x.device, dtype=torch.float32)
             # with the deferred reduction active the same launch also produces the 1x1 conv's weight/bias gradient
             # partials (it holds g and r anyway): no separate wgrad launch for conv[3]
-            batch = WGRAD_BATCH[0]
+            sc = _step_ctx(w2)
             w2_ws = None
-            if (batch is not None and ctx.needs_input_grad[3] and ctx.needs_input_grad[4] and
-                    getattr(w2, "_vq2_grad", None) is not None and getattr(b2, "_vq2_grad", None) is not None):
-                w2_ws, dw2, db2 = batch.resblock_w2(n, h, w, c, s1.co, w2, b2)
+            if (sc is not None and ctx.needs_input_grad[3] and ctx.needs_input_grad[4] and
+                    getattr(w2, "_vq2_grad", None) is not None and getattr(b2, "_vq2_grad", None) is not None and
+                    w2.grad is None and b2.grad is None):
+                w2_ws, dw2, db2 = sc.batch.resblock_w2(n, h, w, c, s1.co, w2, b2)
             check(lib.vq2_resblock_bwd_data(n, h, w, c, s1.co, _p(g), ld_of(g), _p(r), ld_of(r), _p(x), ld_of(x),
                                             _p(packed_weight(s2, w2, PACK_DGRAD)), _p(packed_weight(s1, w1, PACK_DGRAD)),
                                             _p(dh), ld_of(dh), _p(dx), ld_of(dx), _p(w2_ws), _stream()), "resblock_bwd_data")
@@ -679,17 +697,21 @@ class QuantizeFn(Function):
                 raise RuntimeError("QuantizeFn: bad output buffer")
             out = out_buf.view_as(out_buf)
         part = torch.empty(lib.vq2_vq_fwd_workspace_floats(m), device=x.device, dtype=torch.float32)
-        stats = counts = sums_t = None
+        check(lib.vq2_vq_fwd(_p(x), ld_of(x), _p(embed), _p(embed_t), _p(enorm), m, d, k, _p(idx), _p(out), ld_of(out),
+                             _p(part), _stream()), "vq_fwd")
+        stats = None
         if want_stats:
             if stats_buf is not None:
                 if stats_buf.numel() != k + k * d or not stats_buf.is_contiguous():
                     raise RuntimeError("QuantizeFn: stats buffer must be contiguous with K + K*D floats")
-                stats = stats_buf.view_as(stats_buf)  # caller zeroes it
+                stats = stats_buf.view_as(stats_buf)
             else:
-                stats = torch.zeros(k + k * d, device=x.device, dtype=torch.float32)
-            counts, sums_t = stats[:k], stats[k:]
-        check(lib.vq2_vq_fwd(_p(x), ld_of(x), _p(embed), _p(embed_t), _p(enorm), m, d, k, _p(idx), _p(out), ld_of(out),
-                             _p(part), _p(counts), _p(sums_t), _stream()), "vq_fwd")
+                stats = torch.empty(k + k * d, device=x.device, dtype=torch.float32)
+            # every element of stats is written (deterministic sort + ordered sums, no atomics, no zeroing)
+            nbytes = lib.vq2_vq_stats_workspace_bytes(m, d, k)
+            ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.int32)
+            check(lib.vq2_vq_stats(_p(x), ld_of(x), _p(idx), m, d, k, _p(stats[:k]), _p(stats[k:]), _p(ws), nbytes,
+                                   _stream()), "vq_stats")
         diff = torch.empty((), device=x.device, dtype=torch.float32)
         check(lib.vq2_vq_loss(_p(part), m, d, _p(diff), _stream()), "vq_loss")
         ctx.save_for_backward(x, idx, embed_t)

@@ -4,7 +4,8 @@
                  of both quantizers), so Adam is ONE launch and data-parallel training is ONE
                  RCCL all-reduce per step instead of DDP buckets + 4 small ones.
   FusedAdam      torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) math (train_vqvae.py:185)
-  CycleScheduler /root/reference/scheduler.py:221-320 (the only scheduler stage 1 uses)
+  CycleScheduler the only scheduler stage 1 uses (/root/reference/scheduler.py:251-320), as a closed form of
+                 one step counter
 """
 import ctypes as C
 from math import cos, pi
@@ -49,7 +50,7 @@ class ParamArena:
                 p._vq2_grad = self.gp[off:off + p.numel()].view(p.shape)
                 self.offset[id(p)] = off
                 off += sz
-        ops.WEIGHT_EPOCH[0] += 1
+        ops.touch_weights(params)
 
     def grads_ready(self):
         return all(p.grad is not None and p.grad.data_ptr() == p._vq2_grad.data_ptr() for p in self.params)
@@ -77,7 +78,16 @@ class FusedAdam(torch.optim.Optimizer):
         s = ops._stream()
         group = self.param_groups[0]
         lr, (b1, b2), eps = group["lr"], group["betas"], group["eps"]
-        if self.arena is not None and len(self.param_groups) == 1 and self.arena.grads_ready():
+        if self.arena is not None:
+            if len(self.param_groups) != 1:
+                raise RuntimeError("FusedAdam: a ParamArena supports a single param group")
+            if not self.arena.grads_ready():
+                # falling back to the per-tensor path here would silently fork the optimizer state (fresh m/v)
+                missing = [i for i, p in enumerate(self.arena.params)
+                           if p.grad is None or p.grad.data_ptr() != p._vq2_grad.data_ptr()]
+                raise RuntimeError(f"FusedAdam: {len(missing)} gradient(s) did not land in the flat arena (first: "
+                                   f"parameter #{missing[0]}); every arena parameter must receive exactly one "
+                                   "gradient per step (zero_grad() before each backward)")
             self._t += 1
             a = self.arena
             check(lib.vq2_adam_step(ops._p(a.flat_p), ops._p(a.gp), ops._p(self._m), ops._p(self._v), a.n,
@@ -98,72 +108,75 @@ class FusedAdam(torch.optim.Optimizer):
                     check(lib.vq2_adam_step(ops._p(p.data), ops._p(g), ops._p(st["exp_avg"]),
                                             ops._p(st["exp_avg_sq"]), p.numel(), lr, b1, b2, eps, st["step"],
                                             self.grad_scale, s), "adam_step")
-        ops.WEIGHT_EPOCH[0] += 1  # raw-pointer update: invalidate packed weights
+        ops.touch_weights(p for g in self.param_groups for p in g["params"])  # raw-pointer update
         return None
 
 
-# ------------------------------------------------------------------ scheduler.py:221-320
-def anneal_linear(start, end, proportion):
-    return start + proportion * (end - start)
-
-
-def anneal_cos(start, end, proportion):
-    return end + (start - end) / 2 * (cos(pi * proportion) + 1)
-
-
-class Phase:
-    def __init__(self, start, end, n_iter, anneal_fn):
-        self.start, self.end, self.n_iter, self.anneal_fn = start, end, n_iter, anneal_fn
-        self.n = 0
-
-    def step(self):
-        self.n += 1
-        return self.anneal_fn(self.start, self.end, self.n / self.n_iter)
-
-    def reset(self):
-        self.n = 0
-
-    @property
-    def is_done(self):
-        return self.n >= self.n_iter
+# ------------------------------------------------------------------ CycleScheduler
+# fraction of the way STILL TO GO after a proportion u of a segment (1 -> 0): anchoring the value at the segment's
+# end keeps full relative precision where the cosine anneal approaches lr_max/divider/1e4
+_REMAINING = {
+    "linear": lambda u: 1.0 - u,                    # scheduler.py:221-222 (anneal_linear)
+    "cos": lambda u: 0.5 + 0.5 * cos(pi * u),       # scheduler.py:225-228 (anneal_cos)
+}
 
 
 class CycleScheduler:
-    """Linear warm-up then cosine anneal of lr (and optionally beta1), restarting after n_iter."""
+    """The one LR schedule stage 1 uses (/root/reference/scheduler.py:251-320; train_vqvae.py:188-195 builds it
+    with momentum=None, warmup_proportion=0.05): a warm-up segment lr_max/divider -> lr_max over
+    int(n_iter*warmup_proportion) steps, then an anneal segment lr_max -> lr_max/divider/1e4 over the rest, then the
+    cycle restarts; `momentum=(hi, lo)` moves beta1 (or SGD momentum) hi -> lo -> hi along the same segments.
+
+    Same constructor and step() contract as the reference (step() sets param_groups and returns (lr, momentum)),
+    but stateless in form: the whole schedule is a function of ONE counter `t` (steps taken in the current cycle),
+    which is also all that state_dict() has to carry for an exact resume."""
 
     def __init__(self, optimizer, lr_max, n_iter, momentum=(0.95, 0.85), divider=25, warmup_proportion=0.3,
                  phase=("linear", "cos")):
         self.optimizer = optimizer
-        phase1 = int(n_iter * warmup_proportion)
-        phase2 = n_iter - phase1
-        lr_min = lr_max / divider
-        fns = {"linear": anneal_linear, "cos": anneal_cos}
-        self.lr_phase = [Phase(lr_min, lr_max, phase1, fns[phase[0]]),
-                         Phase(lr_max, lr_min / 1e4, phase2, fns[phase[1]])]
         self.momentum = momentum
-        if momentum is not None:
-            m1, m2 = momentum
-            self.momentum_phase = [Phase(m1, m2, phase1, fns[phase[0]]), Phase(m2, m1, phase2, fns[phase[1]])]
-        else:
-            self.momentum_phase = []
-        self.phase = 0
+        warm = int(n_iter * warmup_proportion)
+        self.lengths = (warm, n_iter - warm)
+        self.remaining = (_REMAINING[phase[0]], _REMAINING[phase[1]])
+        lo = lr_max / divider
+        self.lr_ends = ((lo, lr_max), (lr_max, lo / 1e4))
+        self.mom_ends = None if momentum is None else ((momentum[0], momentum[1]), (momentum[1], momentum[0]))
+        self.t = 0
+
+    def values(self, t):
+        """(lr, momentum) after `t` steps of a cycle, 1 <= t <= n_iter."""
+        seg = 0 if t <= self.lengths[0] else 1
+        done = t if seg == 0 else t - self.lengths[0]
+        if self.lengths[seg] == 0:
+            # the reference divides by the segment length on its first step (scheduler.py:241): same failure
+            raise ZeroDivisionError("CycleScheduler: a schedule segment has no iterations (n_iter too small)")
+        w = self.remaining[seg](done / self.lengths[seg])
+        a, b = self.lr_ends[seg]
+        lr = b + (a - b) * w
+        mom = None
+        if self.mom_ends is not None:
+            a, b = self.mom_ends[seg]
+            mom = b + (a - b) * w
+        return lr, mom
 
     def step(self):
-        lr = self.lr_phase[self.phase].step()
-        momentum = self.momentum_phase[self.phase].step() if self.momentum is not None else None
+        if self.lengths[0] == 0:
+            raise ZeroDivisionError("CycleScheduler: the warm-up segment has no iterations (n_iter too small)")
+        self.t += 1
+        lr, mom = self.values(self.t)
         for group in self.optimizer.param_groups:
             group["lr"] = lr
-            if self.momentum is not None:
+            if mom is not None:
                 if "betas" in group:
-                    group["betas"] = (momentum, group["betas"][1])
+                    group["betas"] = (mom, group["betas"][1])
                 else:
-                    group["momentum"] = momentum
-        if self.lr_phase[self.phase].is_done:
-            self.phase += 1
-        if self.phase >= len(self.lr_phase):
-            for ph in self.lr_phase:
-                ph.reset()
-            for ph in self.momentum_phase:
-                ph.reset()
-            self.phase = 0
-        return lr, momentum
+                    group["momentum"] = mom
+        if self.t >= self.lengths[0] + self.lengths[1]:
+            self.t = 0      # the next step starts a new cycle
+        return lr, mom
+
+    def state_dict(self):
+        return {"t": self.t}
+
+    def load_state_dict(self, sd):
+        self.t = int(sd["t"])
