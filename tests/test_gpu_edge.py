@@ -188,6 +188,28 @@ def test_checkpoint_round_trip_reference_format(amd):
     close(a, ref)
 
 
+def _dx_close_up_to_relu_flips(dx, dx_ref, x, st, what, rtol=5e-4, atol=5e-5):
+    """dx must match the oracle element-wise EXCEPT inside the receptive field of a mid-channel pre-activation
+    h = conv3x3(relu(x)) + b1 (vqvae.py:86-87) that sits within fp32 summation error of zero: there the inner ReLU's
+    mask (vqvae.py:88) may legitimately differ between two valid accumulation orders, which moves the 3x3x128
+    input-gradient patch around that pixel by O(|dh|).  Anything else -- e.g. a tile-edge indexing slip, which
+    would look similar in a plain allclose -- fails.  The exception must also stay rare, or the test means nothing."""
+    bad = (dx - dx_ref).abs() > atol + rtol * dx_ref.abs()
+    if not bool(bad.any()):
+        return
+    a = F.relu(x).double()
+    w1, b1 = st["b.conv.1.weight"].double(), st["b.conv.1.bias"].double()
+    hpre = F.conv2d(a, w1, b1, padding=1)                                   # [N,32,H,W] oracle pre-activation
+    mag = F.conv2d(a.abs(), w1.abs(), b1.abs(), padding=1)                  # sum of |terms|: its rounding scale
+    near = (hpre.abs() < 1e-5 * mag).any(1, keepdim=True)                   # [N,1,H,W]
+    assert int(near.sum()) <= max(3, near.numel() // 20000), f"{what}: {int(near.sum())} near-zero pre-activations"
+    field = F.max_pool2d(near.double(), 3, stride=1, padding=1) > 0         # 3x3 footprint of conv3x3's data gradient
+    stray = bad & ~field.expand_as(bad)
+    assert not bool(stray.any()), (f"{what}: {int(stray.sum())} of {int(bad.sum())} mismatching elements lie outside "
+                                   f"the receptive field of a near-zero pre-activation (max err "
+                                   f"{float((dx - dx_ref).abs()[stray].max()):.3e})")
+
+
 @pytest.mark.parametrize("shape", [(1, 13, 21), (2, 8, 16), (3, 5, 40), (5, 64, 64)])
 def test_fused_resblock_forward_backward(amd, shape):
     """One-launch ResBlock (csrc/vq2_resblock.hip; 128/32 channels) vs the oracle's vqvae.py:85-94:
@@ -196,14 +218,13 @@ def test_fused_resblock_forward_backward(amd, shape):
     dev = torch.device("cuda:0")
     n, h, w = shape
     blk = amd.ResBlock(128, 32)
-    # deterministic weights (the default init draws from torch's global RNG): a pre-activation that lands within one
-    # fp32 rounding of zero flips its ReLU mask between the GPU and the CPU summation orders and moves ~500
-    # elements of dx by O(0.01) -- a property of the data, so the data must not change from run to run
+    # seeded weights that differ from shape to shape (the default init would draw from torch's global RNG)
+    tag = f"rb{n}x{h}x{w}"
     with torch.no_grad():
-        blk.conv[1].weight.copy_(t(rng.normal(12, "rb.w1", (32, 128, 3, 3))) * 0.03)
-        blk.conv[1].bias.copy_(t(rng.normal(12, "rb.b1", (32,))) * 0.1)
-        blk.conv[3].weight.copy_(t(rng.normal(12, "rb.w2", (128, 32, 1, 1))) * 0.15)
-        blk.conv[3].bias.copy_(t(rng.normal(12, "rb.b2", (128,))) * 0.1)
+        blk.conv[1].weight.copy_(t(rng.normal(12, tag + ".w1", (32, 128, 3, 3))) * 0.03)
+        blk.conv[1].bias.copy_(t(rng.normal(12, tag + ".b1", (32,))) * 0.1)
+        blk.conv[3].weight.copy_(t(rng.normal(12, tag + ".w2", (128, 32, 1, 1))) * 0.15)
+        blk.conv[3].bias.copy_(t(rng.normal(12, tag + ".b2", (128,))) * 0.1)
     blk.to(dev)
     assert ops.lib.vq2_resblock_supported(128, 32) == 1 and ops.lib.vq2_resblock_supported(32, 8) == 0
     st = {"b.conv.1.weight": blk.conv[1].weight.detach().cpu(), "b.conv.1.bias": blk.conv[1].bias.detach().cpu(),
@@ -229,7 +250,8 @@ def test_fused_resblock_forward_backward(amd, shape):
                 p.grad = None
             y.backward(g_cpu.permute(0, 2, 3, 1).to(dev))
             ref.backward(g_cpu)
-            close(xin.grad.permute(0, 3, 1, 2), xr.grad, rtol=5e-4, atol=5e-5, what="dx")
+            _dx_close_up_to_relu_flips(xin.grad.permute(0, 3, 1, 2).cpu(), xr.grad, x_cpu, st,
+                                       f"dx relu_out={relu_out} sliced={sliced}")
             for name, p in (("b.conv.1.weight", blk.conv[1].weight), ("b.conv.1.bias", blk.conv[1].bias),
                             ("b.conv.3.weight", blk.conv[3].weight), ("b.conv.3.bias", blk.conv[3].bias)):
                 gref = stp[name].grad

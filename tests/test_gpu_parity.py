@@ -460,12 +460,22 @@ def _step_vs_oracle(amd, cfg, size, batch, seed):
             # per-workgroup 1x1 slabs) and the first / last layers
             if exact and (".conv." in k or k.startswith("enc_b.blocks.0") or k.startswith("dec.blocks.6")):
                 gref = ref["grads"][k]
-                close(p.grad, gref, rtol=2e-3, atol=2e-4 * float(gref.abs().max()) + 1e-9, what=k + " (element-wise)")
+                # (first-layer gradients are sums of ~65k cancelling products: their fp32 noise floor is a few 1e-4 of
+                # the largest element whatever the summation order)
+                close(p.grad, gref, rtol=2e-3, atol=5e-4 * float(gref.abs().max()) + 1e-9, what=k + " (element-wise)")
     sd = m.state_dict()
     last_bias = [k for k in st if k.startswith("dec.blocks.") and k.endswith(".bias")][-1]
     for k in ("quantize_t.cluster_size", "quantize_b.cluster_size", "quantize_b.embed_avg", "enc_b.blocks.0.weight",
               last_bias):
-        close(sd[k], st[k], rtol=1e-3 if exact else 5e-2, atol=2e-5 if exact else 2e-2, what=k)
+        got, want = sd[k].cpu(), st[k]
+        if exact and k in ref["grads"]:
+            # first Adam step: the update is lr * g / (|g| + 1e-8), so an element whose gradient sits at the fp32 noise
+            # floor of its sum (see above) may legitimately move anywhere within +-lr; compare those within 2 * lr
+            gref = ref["grads"][k]
+            noisy = gref.abs() < 1e-3 * gref.abs().max()
+            close(got[noisy], want[noisy], rtol=0, atol=6e-4, what=k + " (noise-floor gradients)")
+            got, want = got[~noisy], want[~noisy]
+        close(got, want, rtol=1e-3 if exact else 5e-2, atol=2e-5 if exact else 2e-2, what=k)
 
 
 def test_config4_large_codebook_step_vs_oracle(amd):

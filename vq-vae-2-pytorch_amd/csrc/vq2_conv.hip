@@ -41,6 +41,7 @@ struct ConvGemmParams {
     int relu_in, relu_out;
     int mask_after;       // apply the mask to (acc + residual) instead of to acc alone
     int nbias;            // bias has nbias entries (real output channels)
+    int tap_inner;        // depth order of the uniform-k tiles: 1 = taps innermost (see conv_gemm_fast_kernel)
     double flops, bytes;  // algorithmic work of this launch (for the profiler only)
     unsigned long long *stamps;  // diagnostic build only (STAMP): per-phase cycle totals of workgroup 0
 };
@@ -443,6 +444,24 @@ __global__ __launch_bounds__(256, OCC4 ? 4 : ((MT * NT == 4) ? (BK == 16 ? 3 : 2
     auto load_chunk = [&]() { prep_offsets(); issue_loads(); };
     auto advance_k = [&]() {
         if constexpr (UNI) {
+            // Depth order.  With the channel block innermost (k = (tap, ci) as packed) a workgroup sweeps all Ci
+            // channels of its 128 pixels per tap and comes back to (nearly) the same lines one tap = Ci/BK chunks later:
+            // at four resident workgroups per CU that working set (92 KB per workgroup, 11.8 MB per XCD) falls out of
+            // L1 and of the 4 MiB L2, and every 128-byte line crosses the fabric ~2x per tap (measured 658 MB per launch
+            // for a 67 MB input).  With the TAPS innermost the nine shifted reads of one BK-channel block follow each
+            // other directly (23 KB of whole lines per workgroup, ~2 MB of distinct lines per XCD): most are cache hits.
+            // The sum is the same set of products in another order (the panel offset of a chunk is still (tap*Ci + cb)).
+            if (P.tap_inner) {   // (32-channel block, tap, channel): the block size is fixed so that every tile shape (BK 16
+                u_cb += BK;      // or 32) adds the products in the SAME order -- results do not depend on the tile choice
+                if ((u_cb & 31) == 0) {
+                    u_cb -= 32;
+                    ++u_tap;
+                    if (++u_kw == P.KW) { u_kw = 0; ++u_kh; }
+                    if (u_tap == ntaps) { u_tap = 0; u_kh = 0; u_kw = 0; u_cb += 32; }
+                    refresh_pen();
+                }
+                return;
+            }
             u_cb += BK;
             if (u_cb >= P.Ci) {
                 u_cb = 0; ++u_tap;
@@ -623,7 +642,10 @@ static int launch_conv_gemm_fast(const ConvGemmParams &P, hipStream_t s) {
         name = prof_label("conv_gemm<%dx%dx%d>|M=%d,N=%d,K=%d,k%d,s%d,ph%d", BM, BN, BK, P.M, P.Co, P.K, P.KH, P.stride,
                           P.phases);
     ProfScope prof(name, P.flops, P.bytes, s, BM == 128 && BN == 128);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, P);
+    static const int tapin = tune("VQ2_TAPIN", 1);
+    ConvGemmParams Q = P;
+    Q.tap_inner = (uni && tapin && P.KH * P.KW > 1 && P.Ci > 32 && P.Ci % 32 == 0) ? 1 : 0;
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, Q);
     return check_launch("conv_gemm_fast_kernel");
 }
 
