@@ -197,7 +197,10 @@ int vq2_slice_copy(const float *src, int32_t lds, float *dst, int32_t ldd, int64
  * vq2_vq_prepare: embedT[K,D] and enorm[K] = sum_d embed[d,k]^2      (vqvae.py:47)
  * vq2_vq_fwd:  idx[M] (int64) = first argmin_k ||x||^2 - 2 x.e_k + ||e_k||^2 (vqvae.py:44-49)
  *              out[M,D] = x + (e_idx - x)                            (vqvae.py:52,73)
- *              loss_partial: per-workgroup sums of (e_idx - x)^2     (vqvae.py:72)
+ *              ws (>= vq2_vq_fwd_workspace_floats(M, K) floats): per-128-vector sums of (e_idx - x)^2
+ *              (vqvae.py:72) at its start -- the operand of vq2_vq_loss -- followed by the (distance, index)
+ *              candidates of a K-split search (few vectors x large codebook: splits searched by separate
+ *              workgroups, first minimum taken in code order: same indices as one pass)
  * vq2_vq_stats: counts[K] = one-hot sum, sumsT[K,D] = x rows summed per code   (vqvae.py:55-56)
  *              every element is WRITTEN (no zeroing by the caller) and the result is bit-reproducible:
  *              a stable counting sort of the row numbers by code, then each code's rows are added in
@@ -209,9 +212,9 @@ int vq2_slice_copy(const float *src, int32_t lds, float *dst, int32_t ldd, int64
  * vq2_vq_gather: out[M,D] = embedT[idx]                              (vqvae.py:77-78 embed_code)
  */
 int vq2_vq_prepare(const float *embed, float *embedT, float *enorm, int32_t D, int32_t K, vq2_stream_t stream);
-size_t vq2_vq_fwd_workspace_floats(int64_t M);
+size_t vq2_vq_fwd_workspace_floats(int64_t M, int32_t K);
 int vq2_vq_fwd(const float *x, int32_t ldx, const float *embed, const float *embedT, const float *enorm, int64_t M,
-               int32_t D, int32_t K, int64_t *idx, float *out, int32_t ldo, float *loss_partial, vq2_stream_t stream);
+               int32_t D, int32_t K, int64_t *idx, float *out, int32_t ldo, float *ws, vq2_stream_t stream);
 size_t vq2_vq_stats_workspace_bytes(int64_t M, int32_t D, int32_t K);
 int vq2_vq_stats(const float *x, int32_t ldx, const int64_t *idx, int64_t M, int32_t D, int32_t K, float *counts,
                  float *sumsT, void *ws, size_t ws_bytes, vq2_stream_t stream);

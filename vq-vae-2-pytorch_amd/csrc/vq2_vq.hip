@@ -23,6 +23,41 @@ constexpr int VQ_ROWS = 128;    // latent vectors per loss partial (32 per wave)
 // <DP,16,512>: 512 vectors per workgroup and the reference's whole 512-code codebook (128 KB) staged ONCE, no
 // barrier in the main loop, 16 waves per CU; a quarter of the workgroups also means a quarter of the same-address
 // atomic bursts of the statistics when few codes are in use.  Chosen when the launch still fills every CU.
+// Epilogue shared by the one-pass kernel and the K-split merge: index, gather, straight-through output
+// x + (q - x) (vqvae.py:73), commitment-loss partial per 128 vectors.
+template <int DP, int NW>
+__device__ __forceinline__ void vq_finish(const float (&xf)[DP / 2], int besti, bool rv, int64_t row, int h, int lane,
+                                          int wave, int tid, const float *__restrict__ embedT, int64_t M, int D,
+                                          int64_t *__restrict__ idx_out, float *__restrict__ out, int ldo,
+                                          float *__restrict__ loss_partial, float *wsum) {
+    constexpr int HS = DP / 2;
+    if (rv && h == 0) idx_out[row] = (int64_t)besti;
+    float lsum = 0.f;
+#pragma unroll
+    for (int s = 0; s < HS; s += 4) {
+        const int d = h * HS + s;
+        if (rv && d < D) {
+            const float4 q = *reinterpret_cast<const float4 *>(embedT + (size_t)besti * D + d);
+            const float t0 = q.x - xf[s], t1 = q.y - xf[s + 1], t2 = q.z - xf[s + 2], t3 = q.w - xf[s + 3];
+            lsum += t0 * t0; lsum += t1 * t1; lsum += t2 * t2; lsum += t3 * t3;
+            if (out) {
+                float4 o;
+                o.x = xf[s] + t0; o.y = xf[s + 1] + t1; o.z = xf[s + 2] + t2; o.w = xf[s + 3] + t3;  // vqvae.py:73
+                *reinterpret_cast<float4 *>(out + row * ldo + d) = o;
+            }
+        }
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) wsum[wave] = lsum;
+    __syncthreads();
+    if (tid < NW / 4 && loss_partial && (int64_t)(blockIdx.x * (NW / 4) + tid) * VQ_ROWS < M)   // one partial per 128 vectors
+        loss_partial[blockIdx.x * (NW / 4) + tid] = (wsum[4 * tid] + wsum[4 * tid + 1]) + (wsum[4 * tid + 2] + wsum[4 * tid + 3]);
+}
+
+// K-split (gridDim.y = S > 1): a launch with few latent vectors and a large codebook (the top level of configs[3]:
+// M = 32,768, K = 8,192) would put ONE wave on each SIMD, with nothing to overlap its argmin / staging phases.
+// Split s searches codes [s*kper, (s+1)*kper) and leaves (best distance, best index) in pbest / pidx [S][M];
+// vq_merge_kernel takes the first minimum over the splits in ascending code order -- the same index as one pass.
 template <int DP, int NW, int VQ_CT>
 __global__ __launch_bounds__(64 * NW) void vq_fwd_kernel(const float *__restrict__ x, int ldx,
                                                      const float *__restrict__ embed,   // [D][K]
@@ -30,7 +65,8 @@ __global__ __launch_bounds__(64 * NW) void vq_fwd_kernel(const float *__restrict
                                                      const float *__restrict__ enorm,   // [K]
                                                      int64_t M, int D, int K, int64_t *__restrict__ idx_out,
                                                      float *__restrict__ out, int ldo,
-                                                     float *__restrict__ loss_partial) {
+                                                     float *__restrict__ loss_partial, int kper,
+                                                     float *__restrict__ pbest, int *__restrict__ pidx) {
     constexpr int HS = DP / 2;  // MFMA k-steps; lane half h covers d in [h*HS, (h+1)*HS)
     constexpr int NT = 64 * NW, ROWS = 32 * NW;
     extern __shared__ __attribute__((aligned(16))) float vq_smem[];
@@ -60,22 +96,24 @@ __global__ __launch_bounds__(64 * NW) void vq_fwd_kernel(const float *__restrict
     float best = __builtin_inff();
     int besti = 0;
 
-    for (int ct0 = 0; ct0 < K; ct0 += VQ_CT) {
+    const int kbeg = blockIdx.y * kper;
+    const int kend = (kbeg + kper < K) ? kbeg + kper : K;
+    for (int ct0 = kbeg; ct0 < kend; ct0 += VQ_CT) {
         __syncthreads();
-        // stage E[:, ct0:ct0+128] (zero-padded) and its norms
+        // stage E[:, ct0:ct0+VQ_CT] (zero-padded) and its norms
         for (int t = tid; t < DP * (VQ_CT / 4); t += NT) {
             const int d = t / (VQ_CT / 4), c4 = (t % (VQ_CT / 4)) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (d < D && ct0 + c4 < K) v = *reinterpret_cast<const float4 *>(embed + (size_t)d * K + ct0 + c4);
+            if (d < D && ct0 + c4 < kend) v = *reinterpret_cast<const float4 *>(embed + (size_t)d * K + ct0 + c4);
             *reinterpret_cast<float4 *>(Es + d * VQ_CT + c4) = v;
         }
         // codes past K get norm +inf: their distance never wins, no per-element range test below
-        for (int t = tid; t < VQ_CT; t += NT) En[t] = (ct0 + t < K) ? enorm[ct0 + t] : __builtin_inff();
+        for (int t = tid; t < VQ_CT; t += NT) En[t] = (ct0 + t < kend) ? enorm[ct0 + t] : __builtin_inff();
         __syncthreads();
 
 #pragma unroll 1
         for (int sub = 0; sub < VQ_CT / 32; ++sub) {
-            if (ct0 + sub * 32 >= K) break;
+            if (ct0 + sub * 32 >= kend) break;
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -109,29 +147,44 @@ __global__ __launch_bounds__(64 * NW) void vq_fwd_kernel(const float *__restrict
         const int oi = __shfl_xor(besti, 32, 64);
         if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
     }
-    if (rv && h == 0) idx_out[row] = (int64_t)besti;
+    if (gridDim.y > 1) {
+        if (rv && h == 0) {
+            pbest[(size_t)blockIdx.y * M + row] = best;
+            pidx[(size_t)blockIdx.y * M + row] = besti;
+        }
+        return;
+    }
+    vq_finish<DP, NW>(xf, besti, rv, row, h, lane, wave, tid, embedT, M, D, idx_out, out, ldo, loss_partial, wsum);
+}
 
-    // gather + straight-through output + loss partial
-    float lsum = 0.f;
+template <int DP>
+__global__ __launch_bounds__(256) void vq_merge_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ embedT,
+                                                       int64_t M, int D, int S, const float *__restrict__ pbest,
+                                                       const int *__restrict__ pidx, int64_t *__restrict__ idx_out,
+                                                       float *__restrict__ out, int ldo, float *__restrict__ loss_partial) {
+    constexpr int HS = DP / 2, NW = 4;
+    __shared__ float wsum[NW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const int64_t row = (int64_t)blockIdx.x * (32 * NW) + wave * 32 + col;
+    const bool rv = row < M;
+    float xf[HS];
 #pragma unroll
     for (int s = 0; s < HS; s += 4) {
         const int d = h * HS + s;
-        if (rv && d < D) {
-            const float4 q = *reinterpret_cast<const float4 *>(embedT + (size_t)besti * D + d);
-            const float t0 = q.x - xf[s], t1 = q.y - xf[s + 1], t2 = q.z - xf[s + 2], t3 = q.w - xf[s + 3];
-            lsum += t0 * t0; lsum += t1 * t1; lsum += t2 * t2; lsum += t3 * t3;
-            if (out) {
-                float4 o;
-                o.x = xf[s] + t0; o.y = xf[s + 1] + t1; o.z = xf[s + 2] + t2; o.w = xf[s + 3] + t3;  // vqvae.py:73
-                *reinterpret_cast<float4 *>(out + row * ldo + d) = o;
-            }
-        }
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rv && d < D) v = *reinterpret_cast<const float4 *>(x + row * ldx + d);
+        xf[s] = v.x; xf[s + 1] = v.y; xf[s + 2] = v.z; xf[s + 3] = v.w;
     }
-    lsum = wave_sum(lsum);
-    if (lane == 0) wsum[wave] = lsum;
-    __syncthreads();
-    if (tid < NW / 4 && loss_partial && (int64_t)(blockIdx.x * (NW / 4) + tid) * VQ_ROWS < M)   // one partial per 128 vectors
-        loss_partial[blockIdx.x * (NW / 4) + tid] = (wsum[4 * tid] + wsum[4 * tid + 1]) + (wsum[4 * tid + 2] + wsum[4 * tid + 3]);
+    float best = __builtin_inff();
+    int besti = 0;
+    if (rv)
+        for (int s = 0; s < S; ++s) {   // ascending code ranges + strict '<': the first minimal index wins
+            const float b = pbest[(size_t)s * M + row];
+            const int i = pidx[(size_t)s * M + row];
+            if (b < best) { best = b; besti = i; }
+        }
+    vq_finish<DP, NW>(xf, besti, rv, row, h, lane, wave, tid, embedT, M, D, idx_out, out, ldo, loss_partial, wsum);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -494,12 +547,30 @@ extern "C" int vq2_vq_prepare(const float *embed, float *embedT, float *enorm, i
     return check_launch("vq_prepare_kernel");
 }
 
-extern "C" size_t vq2_vq_fwd_workspace_floats(int64_t M) { return M <= 0 ? 0 : (size_t)((M + VQ_ROWS - 1) / VQ_ROWS); }
+// big = 512-vector workgroups (16 waves, whole 512-code tiles); S = number of K-splits
+static void vq_plan(int64_t M, int32_t K, bool &big, int &S) {
+    big = M >= 512 * 256;   // 512-vector workgroups still cover every CU
+    S = 1;
+    if (!big && K >= 1024) {
+        const int64_t want = (512 * 256 + M - 1) / M;           // splits that bring the launch to one 16-wave workgroup per CU
+        const int64_t most = K / 512;                            // at least one full 512-code tile per split
+        S = (int)(want < most ? want : most);
+        big = S > 1;
+    }
+}
+
+extern "C" size_t vq2_vq_fwd_workspace_floats(int64_t M, int32_t K) {
+    if (M <= 0 || K <= 0) return 0;
+    bool big; int S;
+    vq_plan(M, K, big, S);
+    const size_t nparts = (size_t)((M + VQ_ROWS - 1) / VQ_ROWS);
+    return (nparts + 3) / 4 * 4 + (S > 1 ? (size_t)2 * S * M : 0);
+}
 
 extern "C" int vq2_vq_fwd(const float *x, int32_t ldx, const float *embed, const float *embedT, const float *enorm,
-                          int64_t M, int32_t D, int32_t K, int64_t *idx, float *out, int32_t ldo, float *loss_partial,
+                          int64_t M, int32_t D, int32_t K, int64_t *idx, float *out, int32_t ldo, float *ws,
                           vq2_stream_t stream) {
-    VQ2_REQUIRE(x && embed && embedT && enorm && idx, "vq_fwd: null pointer");
+    VQ2_REQUIRE(x && embed && embedT && enorm && idx && ws, "vq_fwd: null pointer");
     VQ2_REQUIRE(M > 0 && K > 0 && K % 4 == 0 && (D == 4 || D == 8 || D == 16 || D == 32 || D == 64),
                 "vq_fwd: need D in {4,8,16,32,64} and K %% 4 == 0 (D=%d K=%d)", D, K);
     VQ2_REQUIRE(ldx >= D && ldx % 4 == 0 && (!out || (ldo >= D && ldo % 4 == 0)), "vq_fwd: bad pixel strides");
@@ -508,14 +579,24 @@ extern "C" int vq2_vq_fwd(const float *x, int32_t ldx, const float *embed, const
     hipStream_t s = to_stream(stream);
     ProfScope prof(prof_label("vq_fwd|M=%lld,D=%d,K=%d", (long long)M, D, K), 2.0 * (double)M * D * K,
                    4.0 * ((double)M * D * 2 + (double)D * K), s);
-    const bool big = M >= 512 * 256;   // 512-vector workgroups still cover every CU
+    bool big; int S;
+    vq_plan(M, K, big, S);
+    float *loss_partial = ws;
+    const size_t nparts = (size_t)((M + VQ_ROWS - 1) / VQ_ROWS);
+    float *pbest = S > 1 ? ws + (nparts + 3) / 4 * 4 : nullptr;
+    int *pidx = S > 1 ? reinterpret_cast<int *>(pbest + (size_t)S * M) : nullptr;
+    const int kper = S > 1 ? ((K + S - 1) / S + 511) / 512 * 512 : K;
 #define VQ2_LAUNCH_VQ(DP, NW, CT)                                                                                    \
     do {                                                                                                             \
         const size_t lds = ((size_t)DP * CT + CT + NW) * sizeof(float);                                              \
         const unsigned grid = (unsigned)((M + 32 * NW - 1) / (32 * NW));                                             \
         allow_big_lds(vq_fwd_kernel<DP, NW, CT>, lds);                                                               \
-        hipLaunchKernelGGL((vq_fwd_kernel<DP, NW, CT>), dim3(grid), dim3(64 * NW), lds, s, x, ldx, embed, embedT, enorm, M, \
-                           D, K, idx, out, ldo, loss_partial);                                                       \
+        hipLaunchKernelGGL((vq_fwd_kernel<DP, NW, CT>), dim3(grid, S), dim3(64 * NW), lds, s, x, ldx, embed, embedT, enorm, \
+                           M, D, K, idx, out, ldo, loss_partial, kper, pbest, pidx);                                 \
+        if (int e = check_launch("vq_fwd_kernel")) return e;                                                         \
+        if (S > 1)                                                                                                   \
+            hipLaunchKernelGGL((vq_merge_kernel<DP>), dim3((unsigned)((M + 127) / 128)), dim3(256), 0, s, x, ldx, embedT, M, \
+                               D, S, pbest, pidx, idx, out, ldo, loss_partial);                                      \
     } while (0)
     if (D <= 16) { if (big) VQ2_LAUNCH_VQ(16, 16, 512); else VQ2_LAUNCH_VQ(16, 4, 128); }
     else if (D <= 32) { if (big) VQ2_LAUNCH_VQ(32, 16, 512); else VQ2_LAUNCH_VQ(32, 4, 128); }

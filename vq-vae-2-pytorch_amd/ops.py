@@ -696,7 +696,7 @@ class QuantizeFn(Function):
             if tuple(out_buf.shape) != (n, h, w, d) or not is_nhwc_dense(out_buf):
                 raise RuntimeError("QuantizeFn: bad output buffer")
             out = out_buf.view_as(out_buf)
-        part = torch.empty(lib.vq2_vq_fwd_workspace_floats(m), device=x.device, dtype=torch.float32)
+        part = torch.empty(lib.vq2_vq_fwd_workspace_floats(m, k), device=x.device, dtype=torch.float32)
         check(lib.vq2_vq_fwd(_p(x), ld_of(x), _p(embed), _p(embed_t), _p(enorm), m, d, k, _p(idx), _p(out), ld_of(out),
                              _p(part), _stream()), "vq_fwd")
         stats = None
