@@ -193,7 +193,8 @@ def main():
             "roofline": roof,
         }
         if trainer.dp:
-            line["collectives"] = {"backend": dist.get_backend(), "early_tail_buckets": trainer.early_buckets,
+            line["collectives"] = {"backend": dist.get_backend(), "data_path": trainer.comm.name,
+                                   "early_tail_buckets": trainer.early_buckets,
                                    "steps": args.steps + args.warmup}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(size, n_embed)

@@ -244,6 +244,24 @@ int vq2_axpby(const float *a, const float *b, float alpha, float *dst, int64_t n
 /* dst = src * scalar[0] * alpha, scalar read on the device (upstream gradient of a loss) */
 int vq2_scale(const float *src, const float *scalar, float alpha, float *dst, int64_t n, vq2_stream_t stream);
 
+/* ------------------------------------------------------------------ data-parallel exchange (RCCL over xGMI)
+ * One communicator per process (= per GPU), owned by the library -- its only persistent state.  Replaces what
+ * the reference moves with dist.all_reduce at vqvae.py:58-59 (through distributed/distributed.py:64-72: the EMA
+ * sums, SUM) and with DistributedDataParallel at train_vqvae.py:166-171 (gradient all-reduce; initial broadcast
+ * of rank 0's parameters and buffers); bring-up replaces distributed/launch.py:60-66.
+ *   rank 0: vq2_comm_unique_id(id) -> ship the VQ2_COMM_ID_BYTES bytes to every rank (any side channel) ->
+ *   every rank, after selecting its device: vq2_comm_init(id, rank, world).
+ * Collectives are enqueued on `stream` (the caller orders them against compute with events); in place, fp32.
+ * RCCL itself is loaded on first use, so a single-GPU process never needs it. */
+#define VQ2_COMM_ID_BYTES 128
+int vq2_comm_unique_id(void *id);
+int vq2_comm_init(const void *id, int32_t rank, int32_t world);
+int vq2_comm_world(void); /* 0 = no communicator */
+int vq2_comm_rank(void);  /* -1 = no communicator */
+int vq2_comm_allreduce_sum(float *buf, int64_t count, vq2_stream_t stream);
+int vq2_comm_broadcast(float *buf, int64_t count, int32_t root, vq2_stream_t stream);
+int vq2_comm_destroy(void);
+
 /* calibration only: register-resident fp32-MFMA loop (blocks x 256 threads, iters x 32 MFMAs per wave);
  * 2*32*32*2 FLOP per MFMA.  Used by scripts/mfma_peak.py to measure the ceiling the chip sustains. */
 int vq2_debug_mfma_peak(float *scratch, int32_t blocks, int32_t iters, vq2_stream_t stream);

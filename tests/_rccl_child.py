@@ -21,10 +21,13 @@ def main():
     out = sys.argv[1]
     rank, local_rank, world = vqvae2_amd.distributed.bringup("nccl")
     assert world == 1 and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl"
-    info = {}
+    want_native = os.environ.get("VQ2_COMM") == "capi"
+    assert (vqvae2_amd._lib.lib.vq2_comm_world() == 1) == want_native
+    info = {"data_path": vqvae2_amd.distributed.data_comm().name}
     for case in ("tiny", "default64"):
         sd, losses, tr = run_case(vqvae2_amd, case)
         assert tr.dp and tr.comm_stream is not None and tr.split_off is not None
+        assert isinstance(tr.comm, vqvae2_amd.distributed.NativeComm) == want_native
         info[case] = {"early": tr.early_buckets, "losses": losses}
         np.savez(os.path.join(out, f"{case}.npz"), **sd)
     # the mirrored helper over RCCL (distributed.py:64-72 returns the tensor untouched at world size 1)
@@ -35,6 +38,11 @@ def main():
     assert float(t.sum()) == 4.0
     with open(os.path.join(out, "info.json"), "w") as f:
         json.dump(info, f)
+    if want_native:
+        vqvae2_amd.distributed.data_comm().all_reduce(t)   # vq2_comm_allreduce_sum on the current stream
+        torch.cuda.synchronize()
+        assert float(t.sum()) == 4.0
+        assert vqvae2_amd._lib.lib.vq2_comm_destroy() == 0 and vqvae2_amd._lib.lib.vq2_comm_world() == 0
     torch.distributed.destroy_process_group()
 
 

@@ -32,12 +32,16 @@ def _torchrun(script_args, extra_env):
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
 
 
-def test_trainer_over_rccl_world1_equals_plain_run(tmp_path):
+@pytest.mark.parametrize("comm", ["torch", "capi"])
+def test_trainer_over_rccl_world1_equals_plain_run(tmp_path, comm):
+    """comm = "torch": collectives through the torch.distributed "nccl" group; "capi": through libvq2's own
+    communicator (vq2_comm_unique_id / init / allreduce_sum / broadcast / destroy, include/vq2.h)."""
     import vqvae2_amd
     from tests._train_cases import CASES, run_case
-    r = _torchrun([os.path.join(ROOT, "tests", "_rccl_child.py"), str(tmp_path)], {"VQ2_DP_FORCE": "1"})
+    r = _torchrun([os.path.join(ROOT, "tests", "_rccl_child.py"), str(tmp_path)], {"VQ2_DP_FORCE": "1", "VQ2_COMM": comm})
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     info = json.load(open(tmp_path / "info.json"))
+    assert info["data_path"] == ("libvq2 vq2_comm" if comm == "capi" else "torch.distributed")
     for case, (cfg, size, batch, steps, seed) in CASES.items():
         sd, losses, tr = run_case(vqvae2_amd, case)
         assert not tr.dp

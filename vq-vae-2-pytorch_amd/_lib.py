@@ -76,6 +76,13 @@ def _load():
         "vq2_adam_step": (C.c_int, [P, P, P, P, I64, D, D, D, D, I32, D, P]),
         "vq2_axpby": (C.c_int, [P, P, F, P, I64, P]),
         "vq2_scale": (C.c_int, [P, P, F, P, I64, P]),
+        "vq2_comm_unique_id": (C.c_int, [P]),
+        "vq2_comm_init": (C.c_int, [P, I32, I32]),
+        "vq2_comm_world": (C.c_int, []),
+        "vq2_comm_rank": (C.c_int, []),
+        "vq2_comm_allreduce_sum": (C.c_int, [P, I64, P]),
+        "vq2_comm_broadcast": (C.c_int, [P, I64, I32, P]),
+        "vq2_comm_destroy": (C.c_int, []),
         "vq2_debug_mfma_peak": (C.c_int, [P, I32, I32, P]),
         "vq2_debug_set_rb_stamps": (C.c_int, [P]),
         "vq2_debug_set_stamps": (C.c_int, [P]),

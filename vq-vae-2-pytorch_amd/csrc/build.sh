@@ -15,6 +15,8 @@ for f in vq2_conv vq2_wgrad vq2_vq vq2_elem vq2_resblock; do
 done
 $HIPCC $FLAGS -x hip -c "$HERE/vq2_core.cpp" -o "$HERE/_obj/vq2_core.o" &
 pids+=($!)
+$HIPCC $FLAGS -x hip -I/opt/rocm/include -c "$HERE/vq2_comm.cpp" -o "$HERE/_obj/vq2_comm.o" &
+pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done
-$HIPCC -shared -fPIC --offload-arch=gfx950 "$HERE"/_obj/*.o -o "$OUT"
+$HIPCC -shared -fPIC --offload-arch=gfx950 "$HERE"/_obj/*.o -ldl -o "$OUT"
 echo "built $OUT"

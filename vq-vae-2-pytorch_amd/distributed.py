@@ -91,6 +91,72 @@ def data_sampler(dataset, shuffle, distributed):
     return data.RandomSampler(dataset) if shuffle else data.SequentialSampler(dataset)
 
 
+# ---------------------------------------------------------------------------------------------- the data path
+class TorchComm:
+    """Gradient / EMA-sum exchange through the torch.distributed process group ("nccl" = RCCL)."""
+    name = "torch.distributed"
+
+    def all_reduce(self, tensor):
+        dist.all_reduce(tensor)
+
+    def broadcast(self, tensor, src=0):
+        dist.broadcast(tensor, src)
+
+
+class NativeComm:
+    """The same exchange through libvq2's own RCCL communicator (include/vq2.h vq2_comm_*): what a host that is
+    not PyTorch binds.  Collectives are enqueued on the CURRENT stream, like the process-group calls."""
+    name = "libvq2 vq2_comm"
+
+    @staticmethod
+    def _args(tensor):
+        if not (tensor.is_cuda and tensor.dtype == torch.float32 and tensor.is_contiguous()):
+            raise RuntimeError("NativeComm moves contiguous float32 device tensors")
+        import ctypes
+        return ctypes.c_void_p(tensor.data_ptr()), tensor.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def all_reduce(self, tensor):
+        from ._lib import lib, check
+        check(lib.vq2_comm_allreduce_sum(*self._args(tensor)), "comm_allreduce_sum")
+
+    def broadcast(self, tensor, src=0):
+        from ._lib import lib, check
+        ptr, n, stream = self._args(tensor)
+        check(lib.vq2_comm_broadcast(ptr, n, src, stream), "comm_broadcast")
+
+
+_native = None
+
+
+def native_comm_init():
+    """Create libvq2's communicator for this job: rank 0 draws the RCCL unique id and publishes it through the
+    rendezvous store (the process group's, or a TCPStore on MASTER_ADDR:MASTER_PORT when no group exists)."""
+    global _native
+    if _native is not None:
+        return _native
+    import ctypes
+    from ._lib import lib, check
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if _group_up():
+        store = dist.distributed_c10d._get_default_store()
+    else:
+        store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world, is_master=(rank == 0))
+    if rank == 0:
+        buf = ctypes.create_string_buffer(128)
+        check(lib.vq2_comm_unique_id(buf), "comm_unique_id")
+        store.set("vq2_comm_id", buf.raw)
+    uid = store.get("vq2_comm_id")
+    check(lib.vq2_comm_init(ctypes.create_string_buffer(bytes(uid), 128), rank, world), "comm_init")
+    _native = NativeComm()
+    return _native
+
+
+def data_comm():
+    """The communicator Stage1Trainer moves gradients and EMA sums with: libvq2's own when it was brought up
+    (VQ2_COMM=capi), else the torch.distributed group."""
+    return _native if _native is not None else TorchComm()
+
+
 # ---------------------------------------------------------------------------------------------- bring-up
 def bringup(backend="nccl"):
     """Join the job described by the launcher environment: bind this process to its GPU, then create the process
@@ -119,6 +185,8 @@ def bringup(backend="nccl"):
         except Exception as exc:
             raise OSError("failed to initialize NCCL groups") from exc
         synchronize()
+    if gpu and (world > 1 or force) and os.environ.get("VQ2_COMM", "torch") == "capi":
+        native_comm_init()
     return rank, local_rank, world
 
 

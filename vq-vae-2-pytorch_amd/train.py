@@ -60,6 +60,7 @@ class Stage1Trainer:
         self.dp = self.world > 1 or forced
         self.optimizer.grad_scale = 1.0 / self.world  # DDP averages gradients (train_vqvae.py:166-171)
         self.comm_stream = torch.cuda.Stream() if self.dp else None
+        self.comm = dist_fn.data_comm() if self.dp else None   # torch.distributed group or libvq2's own communicator
         if self.dp:
             self._sync_initial_state()
         self.pack_plan.run()
@@ -84,11 +85,11 @@ class Stage1Trainer:
         """What DistributedDataParallel's constructor does (train_vqvae.py:166-171): rank 0's parameters and
         buffers everywhere.  One broadcast for the whole arena, one per tensor outside it (dead dec_ir, codebooks)."""
         with torch.no_grad():
-            dist.broadcast(self.arena.flat_p, 0)
+            self.comm.broadcast(self.arena.flat_p, 0)
             inside = {id(p) for p in self.arena.params}
             for t in list(self.model.parameters()) + list(self.model.buffers()):
                 if id(t) not in inside:
-                    dist.broadcast(t.data, 0)
+                    self.comm.broadcast(t.data, 0)
         ops.touch_weights(self.arena.params)
 
     def _late_grad_ready(self, _param):
@@ -106,7 +107,7 @@ class Stage1Trainer:
         ev = torch.cuda.current_stream().record_event()
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(ev)
-            dist.all_reduce(self.arena.flat_g[self.split_off:])
+            self.comm.all_reduce(self.arena.flat_g[self.split_off:])
         self._bucket_sent = True
         self.early_buckets += 1
 
@@ -145,9 +146,9 @@ class Stage1Trainer:
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
                 if self._bucket_sent:
-                    dist.all_reduce(self.arena.flat_g[:self.split_off])
+                    self.comm.all_reduce(self.arena.flat_g[:self.split_off])
                 else:
-                    dist.all_reduce(self.arena.flat_g)
+                    self.comm.all_reduce(self.arena.flat_g)
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         for q in self.quantizers:
             q.apply_deferred_update()
