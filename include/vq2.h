@@ -197,7 +197,7 @@ int vq2_slice_copy(const float *src, int32_t lds, float *dst, int32_t ldd, int64
  * vq2_vq_prepare: embedT[K,D] and enorm[K] = sum_d embed[d,k]^2      (vqvae.py:47)
  * vq2_vq_fwd:  idx[M] (int64) = first argmin_k ||x||^2 - 2 x.e_k + ||e_k||^2 (vqvae.py:44-49)
  *              out[M,D] = x + (e_idx - x)                            (vqvae.py:52,73)
- *              ws (>= vq2_vq_fwd_workspace_floats(M, K) floats): per-128-vector sums of (e_idx - x)^2
+ *              ws (>= vq2_vq_fwd_workspace_floats(M, D, K) floats): per-128-vector sums of (e_idx - x)^2
  *              (vqvae.py:72) at its start -- the operand of vq2_vq_loss -- followed by the (distance, index)
  *              candidates of a K-split search (few vectors x large codebook: splits searched by separate
  *              workgroups, first minimum taken in code order: same indices as one pass)
@@ -212,7 +212,7 @@ int vq2_slice_copy(const float *src, int32_t lds, float *dst, int32_t ldd, int64
  * vq2_vq_gather: out[M,D] = embedT[idx]                              (vqvae.py:77-78 embed_code)
  */
 int vq2_vq_prepare(const float *embed, float *embedT, float *enorm, int32_t D, int32_t K, vq2_stream_t stream);
-size_t vq2_vq_fwd_workspace_floats(int64_t M, int32_t K);
+size_t vq2_vq_fwd_workspace_floats(int64_t M, int32_t D, int32_t K);
 int vq2_vq_fwd(const float *x, int32_t ldx, const float *embed, const float *embedT, const float *enorm, int64_t M,
                int32_t D, int32_t K, int64_t *idx, float *out, int32_t ldo, float *ws, vq2_stream_t stream);
 size_t vq2_vq_stats_workspace_bytes(int64_t M, int32_t D, int32_t K);
@@ -227,6 +227,22 @@ int vq2_vq_ema_update(float *embed, float *cluster_size, float *embed_avg, const
                       vq2_stream_t stream);
 int vq2_vq_gather(const int64_t *idx, const float *embedT, int64_t M, int32_t D, int32_t K, float *out, int32_t ldo,
                   vq2_stream_t stream);
+
+/* ------------------------------------------------------------------ AdaIN (VQVAE_Deep decoder, vqvae_deep.py:99-134)
+ * vq2_instnorm_stats: mean / rstd [N,C] of nn.InstanceNorm2d(C, affine=False) over the HW pixels of each image
+ *                     (biased variance, rstd = 1/sqrt(var + eps))                            (vqvae_deep.py:102)
+ * vq2_adain_fwd:      y = [relu]((1 + gamma) * (x - mean) * rstd + beta), h = [N, 2C] = (gamma | beta) = fc(style)
+ *                     (vqvae_deep.py:105-109; flags VQ2_RELU_OUT fuses the F.relu_ of vqvae_deep.py:129,131)
+ * vq2_adain_bwd:      dz = dy * (y > 0) (y NULL: no ReLU);  dh[N,2C] = (sum_p dz*xhat | sum_p dz);
+ *                     dx = rstd * (1 + gamma) * (dz - mean_p dz - xhat * mean_p(dz * xhat))
+ * Fixed-order reductions (bit-reproducible).  The fc itself is a 1x1 conv on a [N,1,1,style_dim] tensor. */
+int vq2_instnorm_stats(const float *x, int32_t ldx, int32_t N, int64_t HW, int32_t C, double eps, float *mean,
+                       float *rstd, vq2_stream_t stream);
+int vq2_adain_fwd(const float *x, int32_t ldx, const float *mean, const float *rstd, const float *h, int32_t N,
+                  int64_t HW, int32_t C, int flags, float *y, int32_t ldy, vq2_stream_t stream);
+int vq2_adain_bwd(const float *dy, int32_t lddy, const float *y, int32_t ldy, const float *x, int32_t ldx,
+                  const float *mean, const float *rstd, const float *h, int32_t N, int64_t HW, int32_t C, float *dh,
+                  float *dx, int32_t lddx, vq2_stream_t stream);
 
 /* ------------------------------------------------------------------ loss + optimizer
  * vq2_mse_fwd_bwd: loss = sum((a-b)^2)/denom (train_vqvae.py:31,83) over `numel` contiguous

@@ -20,8 +20,9 @@ import vqvae as ref  # noqa: E402  (the reference module)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import rng  # noqa: E402
 from oracle import vqvae_oracle as O  # noqa: E402
-from oracle.make_golden_cases import (BLOCK_CASES, CONV_FLAVOURS, SCHED_CASES, SEED, block_state,  # noqa: E402
-                                      conv_inputs, quantize_inputs)
+from oracle.make_golden_cases import (BLOCK_CASES, CONV_FLAVOURS, DEEP_ADAIN_CASES, DEEP_CONV_FLAVOURS,  # noqa: E402
+                                      DEEP_EMBED_SCALE, DEEP_GAIN, DEEP_SEED, SCHED_CASES, SEED, block_state, conv_inputs,
+                                      quantize_inputs, thin)
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 def t(a):
@@ -213,6 +214,76 @@ def gen_full256():
     np.savez_compressed(os.path.join(OUT, "full256.npz"), **d)
 
 
+def gen_deep():
+    """VQVAE_Deep (vqvae_deep.py): the tiny configuration end to end (encode -> quantize -> upsample/cat ->
+    decode(quant, style) -> MSE + 0.25*latent -> all gradients), AdaIN alone, the extra conv flavours, an
+    embed_dim-256 Quantize, and the default model's state_dict keys/shapes."""
+    import torch.nn.functional as F
+    import vqvae_deep as refd           # /root/reference/vqvae_deep.py
+    from oracle import vqvae_deep_oracle as OD
+    d = {}
+    # --- layout of the default model
+    big = refd.VQVAE_Deep()
+    d["default.keys"] = np.array(list(big.state_dict().keys()))
+    d["default.shapes"] = np.array([list(v.shape) + [0] * (4 - v.dim()) for v in big.state_dict().values()], np.int64)
+    d["default.n_params"] = np.array(sum(p.numel() for p in big.parameters()), np.int64)
+    del big
+    # --- conv flavours
+    for tag, kind, ws, stride, pad, hw in DEEP_CONV_FLAVOURS:
+        x, w, b = (t(a).requires_grad_(True) for a in conv_inputs(tag, kind, ws, hw))
+        y = (F.conv2d(x, w, b, stride=stride, padding=pad) if kind == "conv" else
+             F.conv_transpose2d(x, w, b, stride=stride, padding=pad))
+        y.backward(t(rng.normal(SEED, f"{tag}.gy", tuple(y.shape))))
+        d.update({f"{tag}.y": n(y), f"{tag}.gx": n(x.grad), f"{tag}.gw": thin(n(w.grad)), f"{tag}.gb": n(b.grad)})
+    # --- Quantize with embed_dim 256
+    d.update(quantize_case("q256_train", 256, 512, (2, 8, 8, 256), True))
+    # --- AdaIN (+ the ReLU that follows it in AdainResBlk)
+    for tag, sd, c, (nb, h, w) in DEEP_ADAIN_CASES:
+        m = refd.AdaIN(sd, c)
+        wt = rng.uniform(DEEP_SEED, f"{tag}.fc.w", (2 * c, sd), -1, 1) / np.sqrt(sd)
+        m.fc.weight.data.copy_(t(wt.astype(np.float32)))
+        m.fc.bias.data.copy_(t(rng.uniform(DEEP_SEED, f"{tag}.fc.b", (2 * c,), -0.5, 0.5)))
+        x = t(rng.normal(DEEP_SEED, f"{tag}.x", (nb, c, h, w)) * 1.5 + 0.3).requires_grad_(True)
+        s = t(rng.normal(DEEP_SEED, f"{tag}.s", (nb, sd))).requires_grad_(True)
+        y = F.relu(m(x, s))
+        y.backward(t(rng.normal(DEEP_SEED, f"{tag}.gy", (nb, c, h, w))))
+        d.update({f"{tag}.y": n(y), f"{tag}.gx": n(x.grad), f"{tag}.gs": n(s.grad), f"{tag}.gw": thin(n(m.fc.weight.grad)),
+                  f"{tag}.gb": n(m.fc.bias.grad)})
+    # --- the tiny model
+    cfg = OD.DEEP_TINY
+    m = refd.VQVAE_Deep(channel=cfg.channel, n_res_block=cfg.n_res_block, n_res_channel=cfg.n_res_channel,
+                        embed_dim=cfg.embed_dim, n_embed=cfg.n_embed, style_dim=cfg.style_dim)
+    st = OD.make_deep_state(cfg, DEEP_SEED, DEEP_EMBED_SCALE, DEEP_GAIN)
+    assert list(st.keys()) == list(m.state_dict().keys())
+    m.load_state_dict(st)
+    m.train()
+    img = O.make_images(2, 32, DEEP_SEED)
+    style = OD.make_style(2, cfg, DEEP_SEED).requires_grad_(True)
+    enc_b, enc_t = m.encode(img)
+    qt, qb, diff, id_t, id_b = m.quantize(enc_b, enc_t)
+    quant = torch.cat([m.upsample_t(qt), qb], 1)
+    dec = m.decode(quant, style)
+    recon = F.mse_loss(dec, img)
+    loss = recon + 0.25 * diff.mean()
+    loss.backward()
+    d.update({"tiny.enc_b": n(enc_b), "tiny.enc_t": n(enc_t), "tiny.quant_t": n(qt), "tiny.quant_b": n(qb),
+              "tiny.diff": n(diff), "tiny.id_t": n(id_t).astype(np.int32), "tiny.id_b": n(id_b).astype(np.int32),
+              "tiny.quant": n(quant), "tiny.dec": n(dec), "tiny.recon": n(recon), "tiny.loss": n(loss),
+              "tiny.g.style": n(style.grad)})
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            d[f"tiny.g.{k}"] = n(p.grad)
+    for k in ("quantize_t.cluster_size", "quantize_b.cluster_size", "quantize_t.embed_avg", "quantize_b.embed",
+              "quantize_t.embed"):
+        d[f"tiny.after.{k}"] = n(m.state_dict()[k])
+    try:        # the fork's forward() calls decode() without its style argument (vqvae_deep.py:277)
+        m(img)
+        d["forward_raises"] = np.array("")
+    except TypeError as e:
+        d["forward_raises"] = np.array(str(e))
+    np.savez_compressed(os.path.join(OUT, "deep.npz"), **d)
+
+
 def gen_scheduler():
     """(lr, momentum) trajectories of the reference's CycleScheduler (scheduler.py:251-320) driving a stock Adam."""
     import scheduler as ref_sched   # /root/reference/scheduler.py
@@ -237,7 +308,7 @@ def gen_scheduler():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["quantize", "convs", "blocks", "tiny", "single", "full", "scheduler"]
+    which = sys.argv[1:] or ["quantize", "convs", "blocks", "tiny", "single", "full", "scheduler", "deep"]
     if "quantize" in which:
         gen_quantize()
     if "convs" in which:
@@ -252,5 +323,7 @@ if __name__ == "__main__":
         gen_full256()
     if "scheduler" in which:
         gen_scheduler()
+    if "deep" in which:
+        gen_deep()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

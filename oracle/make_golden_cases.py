@@ -103,3 +103,25 @@ SCHED_CASES = [
     ("cos_linear", dict(lr_max=1e-2, n_iter=37, momentum=(0.9, 0.8), divider=10, warmup_proportion=0.5,
                         phase=("cos", "linear")), 120),
 ]
+
+
+# VQVAE_Deep: extra conv flavours its decoder needs, an embed_dim-256 Quantize case, AdaIN shapes
+DEEP_CONV_FLAVOURS = [
+    ("t4s2_3_3", "convT", (3, 3, 4, 4), 2, 1, 8),          # up2(out_channel): ConvTranspose2d(3, 3)  (vqvae_deep.py:212)
+    ("c3_512_256", "conv", (256, 512, 3, 3), 1, 1, 4),     # dec.conv1 of the default VQVAE_Deep
+    ("c1_2048_512", "conv", (512, 2048, 1, 1), 1, 0, 1),   # AdaIN's nn.Linear(2048, 512) as a 1x1 conv on a 1x1 image
+]
+DEEP_ADAIN_CASES = [
+    # tag, style_dim, channels, (N, H, W)
+    ("adain_256", 2048, 256, (2, 8, 8)),
+    ("adain_16_odd", 24, 16, (3, 5, 7)),
+]
+DEEP_SEED = 4321
+DEEP_EMBED_SCALE, DEEP_GAIN = 0.3, 2.0     # see vqvae_deep_oracle.make_deep_state
+
+
+def thin(a, limit=65536):
+    """Big gradient tensors are stored as every k-th element of the flattened array (fixture size)."""
+    flat = np.asarray(a).reshape(-1)
+    k = max(1, flat.size // limit)
+    return flat[::k].copy() if k > 1 else np.asarray(a)

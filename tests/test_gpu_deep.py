@@ -1,0 +1,174 @@
+"""GPU parity of the VQVAE_Deep variant against outputs captured from the reference's own
+vqvae_deep.py: the extra conv flavours, Quantize at embed_dim 256, AdaIN (+ReLU) forward/backward, and the tiny
+model end to end through the reference's split API (encode / quantize / upsample_t / decode(quant, style))."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import rng
+from oracle import vqvae_deep_oracle as OD
+from oracle import vqvae_oracle as O
+from oracle.make_golden_cases import (DEEP_ADAIN_CASES, DEEP_CONV_FLAVOURS, DEEP_EMBED_SCALE, DEEP_GAIN, DEEP_SEED, SEED,
+                                      conv_inputs, quantize_inputs, thin)
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def close(a, b, rtol=2e-4, atol=2e-5, what=""):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=what)
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import vqvae2_amd
+    return vqvae2_amd
+
+
+def test_deep_conv_flavours(amd, golden):
+    g = golden("deep")
+    for tag, kind, ws, stride, pad, hw in DEEP_CONV_FLAVOURS:
+        x, w, b = conv_inputs(tag, kind, ws, hw)
+        m = (amd.Conv2d(ws[1], ws[0], ws[2], stride=stride, padding=pad) if kind == "conv" else
+             amd.ConvTranspose2d(ws[0], ws[1], ws[2], stride=stride, padding=pad))
+        m.load_state_dict({"weight": t(w), "bias": t(b)})
+        m.to(DEV)
+        xt = t(x).to(DEV).requires_grad_(True)
+        y = m(xt)
+        close(y, g[f"{tag}.y"], what=f"{tag}.y")
+        y.backward(t(rng.normal(SEED, f"{tag}.gy", tuple(y.shape))).to(DEV))
+        close(xt.grad, g[f"{tag}.gx"], what=f"{tag}.gx")
+        close(thin(m.weight.grad.cpu().numpy()), g[f"{tag}.gw"], rtol=5e-4, atol=1e-4, what=f"{tag}.gw")
+        close(m.bias.grad, g[f"{tag}.gb"], rtol=5e-4, atol=1e-4, what=f"{tag}.gb")
+
+
+def test_quantize_embed_dim_256(amd, golden):
+    g = golden("deep")
+    tag, D, K, xs = "q256_train", 256, 512, (2, 8, 8, 256)
+    x, embed, cs0, gw = quantize_inputs(tag, D, K, xs)
+    q = amd.Quantize(D, K)
+    q.load_state_dict({"embed": t(embed), "cluster_size": t(cs0), "embed_avg": t(embed) * t(cs0)[None, :]})
+    q.to(DEV).train()
+    xt = t(x).to(DEV).requires_grad_(True)
+    out, diff, idx = q(xt)
+    ((out * t(gw).to(DEV)).sum() + 0.25 * diff).backward()
+    assert np.array_equal(idx.cpu().numpy().astype(np.int32), g[f"{tag}.idx"])
+    close(out, g[f"{tag}.out"], rtol=1e-6, atol=1e-6)
+    close(diff, g[f"{tag}.diff"], rtol=1e-5, atol=1e-7)
+    close(xt.grad, g[f"{tag}.xgrad"], rtol=1e-5, atol=1e-7)
+    close(q.cluster_size, g[f"{tag}.cluster_size_after"], rtol=1e-5, atol=1e-6)
+    close(q.embed_avg, g[f"{tag}.embed_avg_after"], rtol=1e-5, atol=1e-5)
+    close(q.embed, g[f"{tag}.embed_after"], rtol=1e-4, atol=1e-5)
+    # ragged row counts and the 128-wide instantiation against the oracle
+    for M, D2, K2 in [(37, 256, 512), (1000, 128, 260), (129, 256, 36)]:
+        xr = t(rng.normal(9, f"d.x{M}", (M, 1, 1, D2)))
+        e = t(rng.normal(9, f"d.e{M}", (D2, K2)))
+        q2 = amd.Quantize(D2, K2)
+        q2.load_state_dict({"embed": e, "cluster_size": torch.zeros(K2), "embed_avg": e.clone()})
+        q2.to(DEV).eval()
+        o2, d2, i2 = q2(xr.to(DEV))
+        ro, rd, ri = O.quantize_forward(xr, e.clone(), torch.zeros(K2), e.clone(), False)
+        margin, _ = O.quantize_margin(xr, e)
+        bad = (i2.cpu() != ri).reshape(-1)
+        assert not bool((bad & (margin > 1e-3)).any()), (M, D2, K2)
+        if not bool(bad.any()):
+            close(o2, ro, rtol=1e-6, atol=1e-6)
+            close(d2, rd, rtol=1e-5, atol=1e-7)
+
+
+def test_adain_relu_forward_backward(amd, golden):
+    g = golden("deep")
+    from vqvae2_amd import vqvae_deep
+    for tag, sd, c, (nb, h, w) in DEEP_ADAIN_CASES:
+        m = vqvae_deep.AdaIN(sd, c)
+        wt = (rng.uniform(DEEP_SEED, f"{tag}.fc.w", (2 * c, sd), -1, 1) / np.sqrt(sd)).astype(np.float32)
+        m.load_state_dict({"fc.weight": t(wt), "fc.bias": t(rng.uniform(DEEP_SEED, f"{tag}.fc.b", (2 * c,), -0.5, 0.5))})
+        m.to(DEV)
+        x = t(rng.normal(DEEP_SEED, f"{tag}.x", (nb, c, h, w)) * 1.5 + 0.3).to(DEV).requires_grad_(True)
+        s = t(rng.normal(DEEP_SEED, f"{tag}.s", (nb, sd))).to(DEV).requires_grad_(True)
+        y = m.nhwc(x.permute(0, 2, 3, 1), s, relu=True).permute(0, 3, 1, 2)       # AdaIN + the F.relu_ of AdainResBlk
+        close(y, g[f"{tag}.y"], what=f"{tag}.y")
+        y.backward(t(rng.normal(DEEP_SEED, f"{tag}.gy", (nb, c, h, w))).to(DEV))
+        close(x.grad, g[f"{tag}.gx"], rtol=5e-4, atol=5e-5, what=f"{tag}.gx")
+        close(s.grad, g[f"{tag}.gs"], rtol=5e-4, atol=5e-5, what=f"{tag}.gs")
+        close(thin(m.fc.weight.grad.cpu().numpy()), g[f"{tag}.gw"], rtol=5e-4, atol=1e-4, what=f"{tag}.gw")
+        close(m.fc.bias.grad, g[f"{tag}.gb"], rtol=5e-4, atol=1e-4, what=f"{tag}.gb")
+        # without the ReLU: plain AdaIN.forward (NCHW in / out) against the oracle
+        st = {"n.fc.weight": t(wt), "n.fc.bias": m.fc.bias.detach().cpu()}
+        close(m(x.detach(), s.detach()), OD.adain(st, "n", x.detach().cpu(), s.detach().cpu()), what=f"{tag} plain")
+
+
+def test_tiny_deep_model_split_api(amd, golden):
+    g = golden("deep")
+    cfg = OD.DEEP_TINY
+    m = amd.VQVAE_Deep(channel=cfg.channel, n_res_block=cfg.n_res_block, n_res_channel=cfg.n_res_channel,
+                       embed_dim=cfg.embed_dim, n_embed=cfg.n_embed, style_dim=cfg.style_dim)
+    m.load_state_dict(OD.make_deep_state(cfg, DEEP_SEED, DEEP_EMBED_SCALE, DEEP_GAIN))
+    m.to(DEV).train()
+    img = O.make_images(2, 32, DEEP_SEED).to(DEV)
+    style = OD.make_style(2, cfg, DEEP_SEED).to(DEV).requires_grad_(True)
+    enc_b, enc_t = m.encode(img)                                   # vqvae_deep.py:282-285
+    close(enc_b, g["tiny.enc_b"], what="enc_b")
+    close(enc_t, g["tiny.enc_t"], what="enc_t")
+    qt, qb, diff, id_t, id_b = m.quantize(enc_b, enc_t)            # :287-301
+    assert tuple(diff.shape) == (1,)
+    assert np.array_equal(id_t.cpu().numpy().astype(np.int32), g["tiny.id_t"])
+    assert np.array_equal(id_b.cpu().numpy().astype(np.int32), g["tiny.id_b"])
+    close(qt, g["tiny.quant_t"], rtol=1e-5, atol=1e-5)
+    close(qb, g["tiny.quant_b"], rtol=1e-5, atol=1e-5)
+    quant = torch.cat([m.upsample_t(qt), qb], 1)                   # :275-276 (caller-side, stock torch.cat)
+    close(quant, g["tiny.quant"])
+    dec = m.decode(quant, style)                                   # :306-307
+    close(dec, g["tiny.dec"], what="dec")
+    recon = F.mse_loss(dec, img)
+    loss = recon + 0.25 * diff.mean()
+    close(loss, g["tiny.loss"], rtol=1e-4)
+    loss.backward()
+    close(style.grad, g["tiny.g.style"], rtol=1e-3, atol=1e-6, what="style grad")
+    for k, p in m.named_parameters():
+        if OD.is_dead_key(k):
+            assert p.grad is None, k
+        else:
+            close(p.grad, g[f"tiny.g.{k}"], rtol=1e-3, atol=2e-6, what=k)
+    for k in ("quantize_t.cluster_size", "quantize_b.cluster_size", "quantize_t.embed_avg", "quantize_b.embed"):
+        close(m.state_dict()[k], g[f"tiny.after.{k}"], rtol=1e-4, atol=1e-5, what=k)
+    # forward(input, style=) and decode_code(..., style=) compose the same pieces
+    m.eval()
+    with torch.no_grad():
+        dec2, diff2, quant2 = m(img, style=style.detach())
+        e_b, e_t = m.encode(img)
+        _, _, _, i_t, i_b = m.quantize(e_b, e_t)
+        dec3 = m.decode_code(i_t, i_b, style=style.detach())
+    close(dec3, dec2, rtol=1e-4, atol=1e-5)
+    with pytest.raises(TypeError):
+        m(img)
+
+
+def test_default_deep_model_runs_one_step(amd):
+    """The default VQVAE_Deep (26.6 M parameters, embed_dim 256, ResBlock(256, 128), AdaIN decoder, style_dim 2048)
+    at 64x64: forward + backward + Adam step with finite results, indices equal to the oracle's outside near-ties."""
+    cfg = OD.DEEP_DEFAULT
+    st = OD.make_deep_state(cfg, 7, 0.3, 1.5)
+    m = amd.VQVAE_Deep()
+    m.load_state_dict(st)
+    m.to(DEV).train()
+    img = O.make_images(2, 64, 7)
+    style = OD.make_style(2, cfg, 7)
+    opt = torch.optim.Adam(m.parameters(), lr=3e-4)
+    dec, diff, quant = m(img.to(DEV), style=style.to(DEV))
+    assert tuple(dec.shape) == (2, 3, 64, 64) and tuple(quant.shape) == (2, 512, 8, 8)
+    loss = F.mse_loss(dec, img.to(DEV)) + 0.25 * diff.mean()
+    loss.backward()
+    opt.step()
+    ref = OD.deep_forward({k: v.clone() for k, v in st.items()}, cfg, img, style, training=True)
+    close(loss, F.mse_loss(ref[0], img) + 0.25 * ref[1].mean(), rtol=2e-3)
+    close(dec, ref[0], rtol=5e-3, atol=5e-3)
+    assert all(torch.isfinite(p).all() for p in m.parameters())

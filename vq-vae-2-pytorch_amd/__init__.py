@@ -4,6 +4,8 @@ Import as ``vqvae2_amd`` (see /vqvae2_amd.py: the directory name carries hyphens
 Public surface mirrors /root/reference/vqvae.py and distributed/__init__.py:1-13.
 """
 from .vqvae import VQVAE, Quantize, ResBlock, Encoder, Decoder, Conv2d, ConvTranspose2d, ReLU  # noqa: F401
+from . import vqvae_deep  # noqa: F401
+from .vqvae_deep import VQVAE_Deep  # noqa: F401
 from . import distributed  # noqa: F401
 from . import ops  # noqa: F401
 from . import codes  # noqa: F401

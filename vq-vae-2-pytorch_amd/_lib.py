@@ -63,7 +63,7 @@ def _load():
         "vq2_resblock_fwd": (C.c_int, [I32, I32, I32, I32, I32, C.c_int, P, I32, P, P, P, P, P, I32, P, I32, P]),
         "vq2_slice_copy": (C.c_int, [P, I32, P, I32, I64, I32, C.c_int, P]),
         "vq2_vq_prepare": (C.c_int, [P, P, P, I32, I32, P]),
-        "vq2_vq_fwd_workspace_floats": (SZ, [I64, I32]),
+        "vq2_vq_fwd_workspace_floats": (SZ, [I64, I32, I32]),
         "vq2_vq_fwd": (C.c_int, [P, I32, P, P, P, I64, I32, I32, P, P, I32, P, P]),
         "vq2_vq_stats_workspace_bytes": (SZ, [I64, I32, I32]),
         "vq2_vq_stats": (C.c_int, [P, I32, P, I64, I32, I32, P, P, P, SZ, P]),
@@ -71,6 +71,9 @@ def _load():
         "vq2_vq_bwd": (C.c_int, [P, I32, P, P, I32, P, P, I64, I32, I32, P, I32, P]),
         "vq2_vq_ema_update": (C.c_int, [P, P, P, P, P, I32, I32, D, D, P, P]),
         "vq2_vq_gather": (C.c_int, [P, P, I64, I32, I32, P, I32, P]),
+        "vq2_instnorm_stats": (C.c_int, [P, I32, I32, I64, I32, D, P, P, P]),
+        "vq2_adain_fwd": (C.c_int, [P, I32, P, P, P, I32, I64, I32, C.c_int, P, I32, P]),
+        "vq2_adain_bwd": (C.c_int, [P, I32, P, I32, P, I32, P, P, P, I32, I64, I32, P, P, I32, P]),
         "vq2_mse_workspace_bytes": (SZ, [I64]),
         "vq2_mse_fwd_bwd": (C.c_int, [P, P, I64, I64, P, P, P, P, SZ, P]),
         "vq2_adam_step": (C.c_int, [P, P, P, P, I64, D, D, D, D, I32, D, P]),

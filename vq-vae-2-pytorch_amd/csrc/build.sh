@@ -7,7 +7,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function"
 mkdir -p "$HERE/_obj"
 pids=()
-for f in vq2_conv vq2_wgrad vq2_vq vq2_elem vq2_resblock; do
+for f in vq2_conv vq2_wgrad vq2_vq vq2_elem vq2_resblock vq2_norm; do
   if [ ! -f "$HERE/_obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/_obj/$f.o" ] || [ "$HERE/vq2_common.h" -nt "$HERE/_obj/$f.o" ] || [ "$HERE/../../include/vq2.h" -nt "$HERE/_obj/$f.o" ]; then
     $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$HERE/_obj/$f.o" ${VQ2_EXTRA_FLAGS:-} &
     pids+=($!)

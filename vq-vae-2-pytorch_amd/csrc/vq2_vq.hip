@@ -548,9 +548,10 @@ extern "C" int vq2_vq_prepare(const float *embed, float *embedT, float *enorm, i
 }
 
 // big = 512-vector workgroups (16 waves, whole 512-code tiles); S = number of K-splits
-static void vq_plan(int64_t M, int32_t K, bool &big, int &S) {
+static void vq_plan(int64_t M, int32_t D, int32_t K, bool &big, int &S) {
     big = M >= 512 * 256;   // 512-vector workgroups still cover every CU
     S = 1;
+    if (D > 64) { big = false; return; }   // embed_dim 128 / 256 (VQVAE_Deep): one 8-wave shape, see vq2_vq_fwd
     if (!big && K >= 1024) {
         const int64_t want = (512 * 256 + M - 1) / M;           // splits that bring the launch to one 16-wave workgroup per CU
         const int64_t most = K / 512;                            // at least one full 512-code tile per split
@@ -559,10 +560,10 @@ static void vq_plan(int64_t M, int32_t K, bool &big, int &S) {
     }
 }
 
-extern "C" size_t vq2_vq_fwd_workspace_floats(int64_t M, int32_t K) {
+extern "C" size_t vq2_vq_fwd_workspace_floats(int64_t M, int32_t D, int32_t K) {
     if (M <= 0 || K <= 0) return 0;
     bool big; int S;
-    vq_plan(M, K, big, S);
+    vq_plan(M, D, K, big, S);
     const size_t nparts = (size_t)((M + VQ_ROWS - 1) / VQ_ROWS);
     return (nparts + 3) / 4 * 4 + (S > 1 ? (size_t)2 * S * M : 0);
 }
@@ -571,8 +572,8 @@ extern "C" int vq2_vq_fwd(const float *x, int32_t ldx, const float *embed, const
                           int64_t M, int32_t D, int32_t K, int64_t *idx, float *out, int32_t ldo, float *ws,
                           vq2_stream_t stream) {
     VQ2_REQUIRE(x && embed && embedT && enorm && idx && ws, "vq_fwd: null pointer");
-    VQ2_REQUIRE(M > 0 && K > 0 && K % 4 == 0 && (D == 4 || D == 8 || D == 16 || D == 32 || D == 64),
-                "vq_fwd: need D in {4,8,16,32,64} and K %% 4 == 0 (D=%d K=%d)", D, K);
+    VQ2_REQUIRE(M > 0 && K > 0 && K % 4 == 0 && D >= 4 && D <= 256 && (D & (D - 1)) == 0,
+                "vq_fwd: need D a power of two in 4..256 and K %% 4 == 0 (D=%d K=%d)", D, K);
     VQ2_REQUIRE(ldx >= D && ldx % 4 == 0 && (!out || (ldo >= D && ldo % 4 == 0)), "vq_fwd: bad pixel strides");
     VQ2_REQUIRE(aligned16(x) && aligned16(embed) && aligned16(embedT) && (!out || aligned16(out)),
                 "vq_fwd: pointers must be 16-byte aligned");
@@ -580,7 +581,7 @@ extern "C" int vq2_vq_fwd(const float *x, int32_t ldx, const float *embed, const
     ProfScope prof(prof_label("vq_fwd|M=%lld,D=%d,K=%d", (long long)M, D, K), 2.0 * (double)M * D * K,
                    4.0 * ((double)M * D * 2 + (double)D * K), s);
     bool big; int S;
-    vq_plan(M, K, big, S);
+    vq_plan(M, D, K, big, S);
     float *loss_partial = ws;
     const size_t nparts = (size_t)((M + VQ_ROWS - 1) / VQ_ROWS);
     float *pbest = S > 1 ? ws + (nparts + 3) / 4 * 4 : nullptr;
@@ -595,10 +596,14 @@ extern "C" int vq2_vq_fwd(const float *x, int32_t ldx, const float *embed, const
                            M, D, K, idx, out, ldo, loss_partial, kper, pbest, pidx);                                 \
         if (int e = check_launch("vq_fwd_kernel")) return e;                                                         \
         if (S > 1)                                                                                                   \
-            hipLaunchKernelGGL((vq_merge_kernel<DP>), dim3((unsigned)((M + 127) / 128)), dim3(256), 0, s, x, ldx, embedT, M, \
-                               D, S, pbest, pidx, idx, out, ldo, loss_partial);                                      \
+            hipLaunchKernelGGL((vq_merge_kernel<(DP <= 64 ? DP : 64)>), dim3((unsigned)((M + 127) / 128)), dim3(256), 0, s,  \
+                               x, ldx, embedT, M, D, S, pbest, pidx, idx, out, ldo, loss_partial);                   \
     } while (0)
-    if (D <= 16) { if (big) VQ2_LAUNCH_VQ(16, 16, 512); else VQ2_LAUNCH_VQ(16, 4, 128); }
+    // D = 128 / 256: this lane's half of the vector is 64 / 128 B-fragment registers, so 8 waves per workgroup
+    // (two per SIMD, <= 256 VGPRs) and code tiles of 256 / 128 (128 KB of LDS)
+    if (D > 128) VQ2_LAUNCH_VQ(256, 8, 128);
+    else if (D > 64) VQ2_LAUNCH_VQ(128, 8, 256);
+    else if (D <= 16) { if (big) VQ2_LAUNCH_VQ(16, 16, 512); else VQ2_LAUNCH_VQ(16, 4, 128); }
     else if (D <= 32) { if (big) VQ2_LAUNCH_VQ(32, 16, 512); else VQ2_LAUNCH_VQ(32, 4, 128); }
     else { if (big) VQ2_LAUNCH_VQ(64, 16, 512); else VQ2_LAUNCH_VQ(64, 4, 128); }
 #undef VQ2_LAUNCH_VQ

@@ -637,6 +637,65 @@ class CatViewFn(Function):
         return g[..., :ctx.ca], gb, None, None
 
 
+class CatFn(Function):
+    """torch.cat([a, b], channel) of two NHWC tensors that already exist (vqvae_deep.py:276,298: the operands are
+    handed in by the caller, so they cannot be produced into slices of one buffer like CatViewFn's): two
+    slice-copy launches forward, slices of the gradient backward."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = as_nhwc(a), as_nhwc(b)
+        n, h, w, ca = a.shape
+        cb = b.shape[3]
+        if tuple(b.shape[:3]) != (n, h, w):
+            raise RuntimeError("CatFn: spatial sizes differ")
+        out = torch.empty((n, h, w, ca + cb), device=a.device, dtype=torch.float32)
+        pix = n * h * w
+        check(lib.vq2_slice_copy(_p(a), ld_of(a), _p(out), ca + cb, pix, ca, 0, _stream()), "slice_copy")
+        check(lib.vq2_slice_copy(_p(b), ld_of(b), _p(out[..., ca:]), ca + cb, pix, cb, 0, _stream()), "slice_copy")
+        ctx.ca = ca
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = as_nhwc(g)
+        return g[..., :ctx.ca], g[..., ctx.ca:]
+
+
+class AdaINFn(Function):
+    """vqvae_deep.py:99-109 (+ the F.relu_ that follows it at :129,131 when relu=True):
+    y = [relu]((1 + gamma) * instance_norm(x) + beta) with (gamma | beta) = h [N, 2C] = fc(style)."""
+
+    @staticmethod
+    def forward(ctx, x, h, relu, eps):
+        x = as_nhwc(x)
+        n, hh, w, c = x.shape
+        _require_cuda(h, "AdaIN style projection")
+        h2 = h.reshape(n, 2 * c)
+        if not h2.is_contiguous():
+            h2 = h2.contiguous()
+        mean = torch.empty((n, c), device=x.device, dtype=torch.float32)
+        rstd = torch.empty((n, c), device=x.device, dtype=torch.float32)
+        y = torch.empty((n, hh, w, c), device=x.device, dtype=torch.float32)
+        check(lib.vq2_instnorm_stats(_p(x), ld_of(x), n, hh * w, c, float(eps), _p(mean), _p(rstd), _stream()), "instnorm_stats")
+        check(lib.vq2_adain_fwd(_p(x), ld_of(x), _p(mean), _p(rstd), _p(h2), n, hh * w, c, VQ2_RELU_OUT if relu else 0,
+                                _p(y), c, _stream()), "adain_fwd")
+        ctx.save_for_backward(x, mean, rstd, h2, y if relu else None)
+        ctx.h_shape = h.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, h2, y = ctx.saved_tensors
+        n, hh, w, c = x.shape
+        g = as_nhwc(dy)
+        dh = torch.empty((n, 2 * c), device=x.device, dtype=torch.float32)
+        dx = torch.empty((n, hh, w, c), device=x.device, dtype=torch.float32)
+        check(lib.vq2_adain_bwd(_p(g), ld_of(g), _p(y), c, _p(x), ld_of(x), _p(mean), _p(rstd), _p(h2), n, hh * w, c,
+                                _p(dh), _p(dx), c, _stream()), "adain_bwd")
+        return dx, dh.reshape(ctx.h_shape), None, None
+
+
 class FanOutFn(Function):
     """One tensor consumed twice (enc_b -> enc_t and the concat, vqvae.py:225,233; quant_t ->
     dec_t and upsample_t, vqvae.py:232,217).  Forward: two aliases; backward: one add kernel."""
@@ -696,7 +755,7 @@ class QuantizeFn(Function):
             if tuple(out_buf.shape) != (n, h, w, d) or not is_nhwc_dense(out_buf):
                 raise RuntimeError("QuantizeFn: bad output buffer")
             out = out_buf.view_as(out_buf)
-        part = torch.empty(lib.vq2_vq_fwd_workspace_floats(m, k), device=x.device, dtype=torch.float32)
+        part = torch.empty(lib.vq2_vq_fwd_workspace_floats(m, d, k), device=x.device, dtype=torch.float32)
         check(lib.vq2_vq_fwd(_p(x), ld_of(x), _p(embed), _p(embed_t), _p(enorm), m, d, k, _p(idx), _p(out), ld_of(out),
                              _p(part), _stream()), "vq_fwd")
         stats = None

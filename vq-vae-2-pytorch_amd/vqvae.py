@@ -100,8 +100,8 @@ class ReLU(nn.Module):
 class Quantize(nn.Module):
     def __init__(self, dim, n_embed, decay=0.99, eps=1e-5):
         super().__init__()
-        if dim not in (4, 8, 16, 32, 64) or n_embed % 4 != 0:
-            raise NotImplementedError("vqvae2_amd.Quantize: dim must be one of 4/8/16/32/64 and n_embed % 4 == 0")
+        if dim not in (4, 8, 16, 32, 64, 128, 256) or n_embed % 4 != 0:
+            raise NotImplementedError("vqvae2_amd.Quantize: dim must be a power of two in 4..256 and n_embed % 4 == 0")
         self.dim = dim
         self.n_embed = n_embed
         self.decay = decay
