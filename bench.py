@@ -203,6 +203,7 @@ def main():
         if args.kernel_table:
             for v in kernels.values():
                 v["tflops"] = round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)
+                v["gbps"] = round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)      # algorithmic bytes / time
                 v["us_per_launch"] = round(v["ms"] * 1e3 / v["launches"], 1)
             with open(args.kernel_table, "w") as f:
                 json.dump(dict(sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])), f, indent=1)

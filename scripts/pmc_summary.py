@@ -27,6 +27,13 @@ for k, c in acc.items():
         e["write_MB_per_launch"] = round(c["WRITE_SIZE"] * 1024 / cnt[k]["WRITE_SIZE"] / 1e6, 1)
     if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c and c["TCC_HIT_sum"] + c["TCC_MISS_sum"] > 0:
         e["l2_hit"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 3)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c and c["GRBM_GUI_ACTIVE"] > 0:
+        # SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of the 1,024 SIMD matrix pipes; GRBM_GUI_ACTIVE sums the
+        # active cycles of the 8 XCDs (MI355X_MICROARCH.md, DVFS note): busy / (active / 8 * 1024) = pipe utilisation
+        e["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 3)
+    for extra in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU_MFMA_MOPS_F32"):
+        if extra in c:
+            e[extra + "_per_launch"] = round(c[extra] / cnt[k][extra])
     res[k] = e
 res = dict(sorted(res.items(), key=lambda kv: -(kv[1].get("fetch_MB_per_launch", 0) + kv[1].get("write_MB_per_launch", 0)) * kv[1]["launches"]))
 json.dump(res, open(out, "w"), indent=1)
