@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 
 import vqvae2_amd  # noqa: E402
 from oracle import vqvae_oracle as O  # noqa: E402
-from tests._train_cases import run_case  # noqa: E402
+from tests._train_cases import run_case, run_dropin_case  # noqa: E402
 
 
 def main():
@@ -30,6 +30,11 @@ def main():
         assert isinstance(tr.comm, vqvae2_amd.distributed.NativeComm) == want_native
         info[case] = {"early": tr.early_buckets, "losses": losses}
         np.savez(os.path.join(out, f"{case}.npz"), **sd)
+    # the reference's own wrapping (train_vqvae.py:166-171): DistributedDataParallel around the drop-in module
+    sd, losses = run_dropin_case(vqvae2_amd, wrap_ddp=True)
+    assert all(k.startswith("module.") for k in sd)            # the key prefix the reference's checkpoints carry
+    info["ddp"] = {"losses": losses}
+    np.savez(os.path.join(out, "ddp.npz"), **sd)
     # the mirrored helper over RCCL (distributed.py:64-72 returns the tensor untouched at world size 1)
     t = torch.ones(4, device="cuda")
     assert vqvae2_amd.distributed.all_reduce(t) is t and float(t.sum()) == 4.0

@@ -52,6 +52,21 @@ def test_trainer_over_rccl_world1_equals_plain_run(tmp_path, comm):
             assert np.array_equal(got[k], v), f"{case}: {k} differs between the RCCL path and the plain path"
 
 
+def test_ddp_wrapped_dropin_module_equals_plain(tmp_path):
+    """the drop-in VQVAE inside nn.parallel.DistributedDataParallel over RCCL (world size 1)
+    trains exactly like the bare module (a one-rank mean is the identity); checkpoints carry DDP's "module." prefix."""
+    import vqvae2_amd
+    from tests._train_cases import run_dropin_case
+    r = _torchrun([os.path.join(ROOT, "tests", "_rccl_child.py"), str(tmp_path)], {"VQ2_DP_FORCE": "1"})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    info = json.load(open(tmp_path / "info.json"))
+    sd, losses = run_dropin_case(vqvae2_amd, wrap_ddp=False)
+    assert info["ddp"]["losses"] == losses
+    got = np.load(tmp_path / "ddp.npz")
+    for k, v in sd.items():
+        assert np.array_equal(got["module." + k], v), k
+
+
 def test_bench_under_torchrun_with_rccl_group():
     r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "tiny",
                    "--no-cpu-baseline"], {"VQ2_DP_FORCE": "1"})
