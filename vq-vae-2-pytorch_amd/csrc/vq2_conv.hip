@@ -20,6 +20,7 @@
 // ConvTranspose2d(k4,s2,p1) and the data-gradient of a stride-2 4x4 conv are the same
 // sub-pixel decomposition: 4 output phases, each a 2x2 stride-1 conv; blockIdx.z = phase.
 #include "vq2_common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace vq2 {
@@ -42,6 +43,8 @@ struct ConvGemmParams {
     int mask_after;       // apply the mask to (acc + residual) instead of to acc alone
     int nbias;            // bias has nbias entries (real output channels)
     int tap_inner;        // depth order of the uniform-k tiles: 1 = taps innermost (see conv_gemm_fast_kernel)
+    int c4_tpw;           // conv_k4s2_c4_kernel: tiles per workgroup
+    int ci_real;          // real input channels (<= Ci; the rest are zero padding), 0 = Ci
     double flops, bytes;  // algorithmic work of this launch (for the profiler only)
     unsigned long long *stamps;  // diagnostic build only (STAMP): per-phase cycle totals of workgroup 0
 };
@@ -876,6 +879,207 @@ static int launch_subpixel(const ConvGemmParams &P, hipStream_t s) {
     return check_launch("subpixel_conv_kernel");
 }
 
+// ====================================================================== k4 s2 p1 conv out of 4 (3 + pad) channels
+// The image-side layers -- Conv2d(3 -> 64, k4 s2 p1) forward (vqvae.py:105) and the data gradient of the
+// reconstruction ConvTranspose2d(64 -> 3) (vqvae.py:157), which is the same strided conv of the 4-channel dy -- have a
+// depth of only K = 16 taps x 4 channels = 64: as an implicit GEMM with staged chunks they are all prologue and
+// epilogue (2.2-2.8 TB/s of algorithmic bytes on the generic tile).  They are HBM-bound (AI ~ 20): this kernel keeps
+// the whole 64 x 64 weight panel in registers, stages the 18 x 34-pixel input patch of an 8 x 16 output tile in LDS
+// (one 16-byte pixel = one tap of the depth: a fragment read IS the im2col), walks four tiles per workgroup with the
+// next tile's patch in flight behind the current tile's MFMAs, and swaps the operand roles (weights = MFMA rows,
+// pixels = columns) so that a lane ends up with 4 CONSECUTIVE output channels of one pixel: bias, mask and store are
+// 16-byte accesses (8 stores per lane instead of 32).
+namespace c4 {
+constexpr int TH = 8, TW = 16;                    // output pixels per tile
+constexpr int PH = 2 * TH + 2, PW = 2 * TW + 2;   // input patch
+constexpr int NP = PH * PW;                       // 612 pixels of 16 bytes
+constexpr int P_LD = (NP + 255) / 256;            // 3 patch loads per thread
+constexpr int COOB = 0x7F000000;
+}  // namespace c4
+
+template <bool HAS_MASK, bool SWAP, bool C4>
+__global__ __launch_bounds__(256, 3) void conv_k4s2_c4_kernel(const ConvGemmParams P) {
+    using namespace c4;
+    __shared__ float4 patch[NP];
+    const int tid = threadIdx.x, lane = tid & 63, wq = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int tiles_x = (P.Wo + TW - 1) / TW, tiles_y = (P.Ho + TH - 1) / TH;
+    const int tiles = tiles_x * tiles_y, total = P.N * tiles;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x), 0, P.N * P.H * P.W * P.ldx * 4, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.w), 0, 64 * 64 * 4, RSRC_FLAGS);
+    const int ybytes = P.N * P.Ho * P.Wo * 4;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(P.y, 0, ybytes * P.ldy, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rmk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(HAS_MASK ? P.mask : P.y), 0,
+                                                                         HAS_MASK ? ybytes * P.ldm : 0, RSRC_FLAGS);
+    // weight fragments (MFMA A operand): row co = 32*j + l31, depth k = 8*k8 + 4*h .. +3  (panel [Co][tap][Ci] = [64][64])
+    float4 wf[2][8];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8)
+            wf[j][k8] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rw, ((j * 32 + l31) * 64 + 8 * k8 + 4 * h) * 4, 0, 0));
+    // bias (zero-padded to 64) in LDS: the epilogue reads this lane's 4 consecutive channels as one float4
+    __shared__ __attribute__((aligned(16))) float bias_s[64];
+    if (tid < 64) bias_s[tid] = (P.bias && tid < P.nbias) ? P.bias[tid] : 0.f;
+    const bool relu_in = P.relu_in != 0;
+    u32x4 pr[P_LD];
+    auto tile_of = [&](int v, int &n, int &y0, int &x0) {
+        n = v / tiles;
+        const int t = v - n * tiles;
+        const int tyi = t / tiles_x;
+        y0 = tyi * TH; x0 = (t - tyi * tiles_x) * TW;
+    };
+    auto issue_patch = [&](int v) {
+        int n, y0, x0;
+        tile_of(v, n, y0, x0);
+#pragma unroll
+        for (int q = 0; q < P_LD; ++q) {
+            const int f = tid + 256 * q;
+            const int prow = f / PW, pcol = f - prow * PW;
+            const int gy = 2 * y0 - 1 + prow, gx = 2 * x0 - 1 + pcol;
+            const bool ok = v < total && f < NP && (unsigned)gy < (unsigned)P.H && (unsigned)gx < (unsigned)P.W;
+            pr[q] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? ((n * P.H + gy) * P.W + gx) * P.ldx * 4 : COOB, 0, 0);
+        }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int q = 0; q < P_LD; ++q) {
+            const int f = tid + 256 * q;
+            if (f < NP) patch[f] = relu_in ? relu4(as_f4(pr[q])) : as_f4(pr[q]);
+        }
+    };
+    const int TPW = P.c4_tpw;
+    const int v0 = xcd_remap(blockIdx.x, gridDim.x) * TPW;   // consecutive tiles of one image row band per workgroup
+    issue_patch(v0);
+    const int ty = 2 * wq + (l31 >> 4), tx = l31 & 15;       // this lane's output pixel inside a tile (MFMA column l31)
+    for (int it = 0; it < TPW; ++it) {
+        const int v = v0 + it;
+        if (v >= total) break;
+        store_patch();
+        __syncthreads();
+        if (it + 1 < TPW) issue_patch(v + 1);                 // in flight behind this tile's MFMAs and stores
+        int n, y0, x0;
+        tile_of(v, n, y0, x0);
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        u32x4 mk[2][4];
+        if (HAS_MASK && SWAP) {    // the mask of this lane's 16 outputs, requested BEHIND the MFMAs instead of after them
+            const int oy = y0 + ty, ox = x0 + tx;
+            const bool pv = oy < P.Ho && ox < P.Wo;
+            const int pix = (n * P.Ho + oy) * P.Wo + ox;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    mk[j][g] = __builtin_amdgcn_raw_buffer_load_b128(rmk, pv ? pix * P.ldm * 4 + (32 * j + 8 * g + 4 * h) * 4 : COOB, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) {
+            // depth 8*k8 + 4*h .. +3 = the 4 channels of tap 2*k8 + h: kh = k8/2, kw = 2*(k8&1) + h
+            const float4 a = patch[(2 * ty + (k8 >> 1)) * PW + 2 * tx + 2 * (k8 & 1) + h];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                // the 4th channel is zero padding on both operands when the layer has 3 real channels: its product
+                // adds an exact 0 and is skipped (a quarter of the matrix work)
+                if (SWAP) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[j][k8].x, a.x, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[j][k8].y, a.y, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[j][k8].z, a.z, acc[j], 0, 0, 0);
+                    if (C4) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[j][k8].w, a.w, acc[j], 0, 0, 0);
+                } else {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wf[j][k8].x, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wf[j][k8].y, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wf[j][k8].z, acc[j], 0, 0, 0);
+                    if (C4) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wf[j][k8].w, acc[j], 0, 0, 0);
+                }
+            }
+        }
+        const int relu_floor_bits = P.relu_out ? 0 : (int)0x80000000;
+        if (SWAP) {
+            // epilogue: lane = pixel (ty, tx); registers 4g..4g+3 of block j = channels 32*j + 8*g + 4*h + (0..3)
+            const int oy = y0 + ty, ox = x0 + tx;
+            const bool pv = oy < P.Ho && ox < P.Wo;
+            const int pix = (n * P.Ho + oy) * P.Wo + ox;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co4 = (32 * j + 8 * g + 4 * h) * 4;
+                    const float4 bv = *reinterpret_cast<const float4 *>(bias_s + 32 * j + 8 * g + 4 * h);
+                    float4 o = make_float4(acc[j][4 * g] + bv.x, acc[j][4 * g + 1] + bv.y, acc[j][4 * g + 2] + bv.z,
+                                           acc[j][4 * g + 3] + bv.w);
+                    if (HAS_MASK) {
+                        const float4 m = as_f4(mk[j][g]);
+                        o.x = m.x > 0.f ? o.x : 0.f; o.y = m.y > 0.f ? o.y : 0.f; o.z = m.z > 0.f ? o.z : 0.f; o.w = m.w > 0.f ? o.w : 0.f;
+                    }
+                    o.x = relu_floor(o.x, relu_floor_bits); o.y = relu_floor(o.y, relu_floor_bits);
+                    o.z = relu_floor(o.z, relu_floor_bits); o.w = relu_floor(o.w, relu_floor_bits);
+                    u32x4 u;
+                    u.x = __float_as_uint(o.x); u.y = __float_as_uint(o.y); u.z = __float_as_uint(o.z); u.w = __float_as_uint(o.w);
+                    __builtin_amdgcn_raw_buffer_store_b128(u, ry, pv ? pix * P.ldy * 4 + co4 : COOB, 0, 0);
+                }
+        } else {
+            // lane = channel l31 (+32 j); register r = pixel 4*h + (r&3) + 8*(r>>2) of this wave's 32
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pp = 4 * h + (r & 3) + 8 * (r >> 2);
+                const int oy = y0 + 2 * wq + (pp >> 4), ox = x0 + (pp & 15);
+                const bool pv = oy < P.Ho && ox < P.Wo;
+                const int pix = (n * P.Ho + oy) * P.Wo + ox;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int co4 = (32 * j + l31) * 4;
+                    float v = acc[j][r] + bias_s[32 * j + l31];
+                    if (HAS_MASK) {
+                        const float m = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rmk, pv ? pix * P.ldm * 4 + co4 : COOB, 0, 0));
+                        v = m > 0.f ? v : 0.f;
+                    }
+                    v = relu_floor(v, relu_floor_bits);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, pv ? pix * P.ldy * 4 + co4 : COOB, 0, 0);
+                }
+            }
+        }
+        __syncthreads();   // every wave is done reading the patch before the next tile overwrites it
+    }
+}
+
+static bool conv_c4_ok(const ConvGemmParams &P) {
+    const long big = 0x7F000000L / 4;
+    return P.phases == 1 && P.KH == 4 && P.KW == 4 && P.stride == 2 && P.pad_h == 1 && P.pad_w == 1 && P.Ci == 4 &&
+           P.Co == 64 && !P.res && P.H % 2 == 0 && P.W % 2 == 0 && P.ldy % 4 == 0 && (!P.mask || P.ldm % 4 == 0) &&
+           (long)P.N * P.H * P.W * P.ldx < big && (long)P.N * P.Ho * P.Wo * (P.ldy > P.ldm ? P.ldy : P.ldm) < big &&
+           (reinterpret_cast<uintptr_t>(P.y) & 15u) == 0 && (!P.mask || (reinterpret_cast<uintptr_t>(P.mask) & 15u) == 0);
+}
+
+static int launch_conv_c4(const ConvGemmParams &P, hipStream_t s) {
+    const int tiles = ((P.Wo + c4::TW - 1) / c4::TW) * ((P.Ho + c4::TH - 1) / c4::TH) * P.N;
+    const char *name = "conv_k4s2_c4";
+    if (prof_enabled()) name = prof_label("conv_k4s2_c4|M=%d,N=%d,K=%d%s", P.M, P.Co, P.K, P.mask ? ",mask" : "");
+    ProfScope prof(name, P.flops, P.bytes, s);
+    // measured (scripts/microbench.py c4s2_3_64 / t_64_3; generic tile: 75 / 88 us): the plain layer streams best with
+    // coalesced 4-byte stores and 4 tiles per workgroup (45 us, 3.7 TB/s of algorithmic bytes); the masked one with the
+    // 16-byte form whose mask loads sit behind the MFMAs and 8 tiles per workgroup (72 us, 4.2 TB/s)
+    static const int swap_m = tune("VQ2_C4_SWAP_MASK", 1), swap_p = tune("VQ2_C4_SWAP", 0);
+    static const int tpw_m = tune("VQ2_C4_TPW_MASK", 8), tpw_p = tune("VQ2_C4_TPW", 4);
+    const bool swap = P.mask ? swap_m : swap_p;
+    const int tpw = P.mask ? tpw_m : tpw_p;
+    const bool c4 = !(P.ci_real > 0 && P.ci_real <= 3);
+    auto pick = [&](auto m, auto sw) {
+        constexpr bool M = decltype(m)::value, S = decltype(sw)::value;
+        return c4 ? conv_k4s2_c4_kernel<M, S, true> : conv_k4s2_c4_kernel<M, S, false>;
+    };
+    auto kern = P.mask ? (swap ? pick(std::true_type{}, std::true_type{}) : pick(std::true_type{}, std::false_type{}))
+                       : (swap ? pick(std::false_type{}, std::true_type{}) : pick(std::false_type{}, std::false_type{}));
+    ConvGemmParams Q = P;
+    Q.c4_tpw = tpw < 1 ? 1 : tpw;
+    hipLaunchKernelGGL(kern, dim3((tiles + Q.c4_tpw - 1) / Q.c4_tpw), dim3(256), 0, s, Q);
+    return check_launch("conv_k4s2_c4_kernel");
+}
+
 static unsigned long long *g_stamps = nullptr;  // set by vq2_debug_set_stamps: diagnostic cycle stamps
 
 static int tune(const char *name, int dflt) {
@@ -896,6 +1100,8 @@ static int run_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
     const bool fast_ok = fast && P.KH * P.KW <= 32 && (long)P.N * P.H * P.W * P.ldx < lim &&
                          (long)P.N * P.Hy * P.Wy * P.ldy < lim && (long)P.N * P.Hy * P.Wy * (P.ldm > P.ldr ? P.ldm : P.ldr) < lim &&
                          (long)P.Co * P.K * P.phases < lim;
+    static const int c4k = tune("VQ2_C4", 1);
+    if (c4k && fast_ok && !g_stamps && conv_c4_ok(P)) return launch_conv_c4(P, s);
     static const int subpix = tune("VQ2_SUBPIX", 1);
     const long big = 0x7F000000L / 4;   // the patch kernel's out-of-range sentinel must stay above every tensor
     // (a launch of <= 256 workgroups with a short depth is better off with the 64-row GEMM tiles: measured)
@@ -1342,6 +1548,7 @@ extern "C" int vq2_conv_fwd(const vq2_conv_desc *d, int flags, const float *x, c
     P.Co = d->Co; P.ldy = d->ldy; P.ldr = ldres; P.ldm = 0;
     P.relu_in = (flags & VQ2_RELU_IN) != 0; P.relu_out = (flags & VQ2_RELU_OUT) != 0;
     P.nbias = d->Cor ? d->Cor : d->Co;
+    P.ci_real = d->Cir ? d->Cir : d->Ci;
     out_dims(d, P.Hy, P.Wy);
     if (!d->transposed) {
         P.KH = d->KH; P.KW = d->KW; P.stride = d->stride; P.pad_h = P.pad_w = d->pad;
@@ -1384,6 +1591,7 @@ extern "C" int vq2_conv_dgrad_ex(const vq2_conv_desc *d, int flags, const float 
     P.N = d->N; P.H = Hy; P.W = Wy; P.Ci = d->Co; P.ldx = d->ldy;
     P.Co = d->Ci; P.ldy = lddx; P.ldm = ldmask; P.ldr = ldres;
     P.relu_in = 0; P.relu_out = 0;
+    P.ci_real = d->Cor ? d->Cor : d->Co;   // the gradient GEMM's input channels are the forward op's output channels
     P.mask_after = (flags & VQ2_MASK_AFTER_RESIDUAL) != 0;
     P.Hy = d->H; P.Wy = d->W;
     if (!d->transposed && d->stride == 1) {
