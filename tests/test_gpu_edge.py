@@ -263,3 +263,47 @@ def test_fused_resblock_forward_backward(amd, shape):
     finally:
         ops.RESBLOCK_FUSED[0] = True
     close(y2, blk.nhwc(xin.detach(), relu_out=True), rtol=1e-5, atol=1e-5)
+
+
+def test_vq_stats_shapes_patterns_and_determinism(amd):
+    """vq2_vq_stats (deterministic EMA statistics) driven directly with synthetic index patterns: chunk / block
+    boundaries (63..1025 rows), one code for every row, one row per code, sorted and random assignments, a channel
+    slice as input, D from 4 to 256 -- exact counts, sums against index_add, bit-identical on a second call."""
+    import ctypes as C
+    from vqvae2_amd import ops
+    lib = ops.lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    for M, D, K in [(1, 4, 4), (63, 16, 36), (64, 64, 512), (65, 64, 512), (1023, 8, 12), (1024, 64, 64), (1025, 32, 512),
+                    (5000, 256, 100), (4099, 128, 8192), (70000, 64, 16)]:
+        patterns = {
+            "same": torch.full((M,), K - 1, dtype=torch.int64),
+            "round": torch.arange(M, dtype=torch.int64) % K,
+            "sorted": (torch.arange(M, dtype=torch.int64) * K) // M,
+            "random": torch.randint(0, K, (M,), generator=g),
+            "skewed": torch.minimum(torch.randint(0, K, (M,), generator=g), torch.randint(0, K, (M,), generator=g)) // 3,
+        }
+        wide = torch.randn(M, D + 8, generator=g)
+        for name, idx in patterns.items():
+            for sliced in (False, True):
+                xh = wide[:, 4:4 + D] if sliced else wide[:, :D].contiguous()
+                xd = wide.to(dev)[:, 4:4 + D] if sliced else xh.to(dev)
+                ld = D + 8 if sliced else D
+                idx_d = idx.to(dev)
+                outs = []
+                for _ in range(2):
+                    stats = torch.full((K + K * D,), float("nan"), device=dev)      # every element must be written
+                    nbytes = lib.vq2_vq_stats_workspace_bytes(M, D, K)
+                    ws = torch.empty(nbytes // 4, device=dev, dtype=torch.int32)
+                    ops.check(lib.vq2_vq_stats(C.c_void_p(xd.data_ptr()), ld, C.c_void_p(idx_d.data_ptr()), M, D, K,
+                                               C.c_void_p(stats.data_ptr()), C.c_void_p(stats[K:].data_ptr()),
+                                               C.c_void_p(ws.data_ptr()), nbytes, None), "vq_stats")
+                    torch.cuda.synchronize()
+                    outs.append(stats.cpu())
+                assert torch.equal(outs[0], outs[1]), (M, D, K, name, sliced)
+                counts = torch.bincount(idx, minlength=K).float()
+                sums = torch.zeros(K, D, dtype=torch.float64).index_add_(0, idx, xh.double())
+                assert torch.equal(outs[0][:K], counts), (M, D, K, name)
+                np.testing.assert_allclose(outs[0][K:].reshape(K, D).numpy(), sums.numpy(), rtol=2e-5,
+                                           atol=2e-5 * float(xh.abs().max()) * max(1.0, float(counts.max()) ** 0.5),
+                                           err_msg=f"{(M, D, K, name, sliced)}")
