@@ -104,7 +104,10 @@ def test_quantize_8192_golden(amd, golden):
 
 def test_quantize_ragged_and_embed_code(amd):
     # M not a multiple of the 128-row workgroup tile, several tiny shapes, eval mode
-    for M, D, K in [(1, 64, 512), (37, 64, 512), (129, 16, 64), (1000, 32, 128), (300, 8, 36), (5, 4, 4)]:
+    # (the K >= 1024 cases take the K-split search: code ranges searched by separate workgroups + vq_merge_kernel,
+    #  including a last split that starts past K)
+    for M, D, K in [(1, 64, 512), (37, 64, 512), (129, 16, 64), (1000, 32, 128), (300, 8, 36), (5, 4, 4),
+                    (300, 64, 1540), (77, 16, 2052), (129, 32, 4096), (3000, 64, 1024)]:
         x = t(rng.normal(7, f"r.x{M}", (M, 1, 1, D)))
         e = t(rng.normal(7, f"r.e{M}", (D, K)))
         q = amd.Quantize(D, K)
