@@ -114,3 +114,32 @@ def test_example_scripts_train_then_extract(tmp_path):
     top, bottom, fname = ds[6]
     assert fname == "batch1.npy:2" and top.dtype == torch.int64 and tuple(top.shape) == (8, 8) and tuple(bottom.shape) == (16, 16)
     assert torch.equal(top, id_t[2].cpu()) and torch.equal(bottom, id_b[2].cpu())
+
+
+def test_gradient_accumulation_and_arena_guards():
+    """With a ParamArena active, a second backward without zero_grad must ACCUMULATE (old + new), not overwrite the
+    slot that p.grad aliases; and FusedAdam refuses to fork its state when a gradient missed the arena."""
+    import vqvae2_amd as amd
+    m, tr = _trainer(amd, 21)
+    img = O.make_images(2, 32, 970).cuda()
+    crit = torch.nn.MSELoss()
+
+    def backward_once():
+        dec, diff = m(img)
+        (crit(dec, img) + 0.25 * diff.mean()).backward()
+
+    m.train()
+    tr.arena.zero_grad()
+    backward_once()
+    g1 = {k: p.grad.clone() for k, p in m.live_named_parameters()}
+    backward_once()                                   # accumulates into the same .grad tensors
+    for k, p in m.live_named_parameters():
+        # the trainer defers the EMA update, so both passes see the same codebooks: the sum is exactly twice the first
+        assert torch.equal(p.grad, 2 * g1[k]), k
+    # a gradient that does not live in the arena: the fused optimizer must raise instead of silently re-creating m/v
+    tr.arena.zero_grad()
+    backward_once()
+    p0 = tr.arena.params[0]
+    p0.grad = p0.grad.clone()
+    with pytest.raises(RuntimeError, match="did not land in the flat arena"):
+        tr.optimizer.step()
