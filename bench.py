@@ -127,6 +127,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # "recon-MSE parity" half of the BASELINE metric, recorded with the number: the first two images through the HIP
+    # path and through the CPU oracle (eval forward: same weights, same codebooks), outside the timed region
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import torch.nn.functional as F
+        st0 = O.make_state(cfg, 1234)
+        model.eval()
+        with torch.no_grad():
+            dec_g, _ = model(img[:2])
+            _, _, _, idt_g, idb_g = model.encode(img[:2])
+            dec_c, _, idt_c, idb_c = O.vqvae_forward(st0, cfg, img[:2].cpu(), training=False)
+        model.train()
+        parity = {"images": 2,
+                  "recon_mse_hip": float(F.mse_loss(dec_g, img[:2])), "recon_mse_cpu": float(F.mse_loss(dec_c, img[:2].cpu())),
+                  "dec_max_abs_diff": float((dec_g.cpu() - dec_c).abs().max()),
+                  "index_mismatches": int((idt_g.cpu() != idt_c).sum() + (idb_g.cpu() != idb_c).sum()),
+                  "indices": int(idt_c.numel() + idb_c.numel())}
+
     for _ in range(args.warmup):
         out = trainer.step(img)
     barrier()
@@ -196,6 +214,8 @@ def main():
             line["collectives"] = {"backend": dist.get_backend(), "data_path": trainer.comm.name,
                                    "early_tail_buckets": trainer.early_buckets,
                                    "steps": args.steps + args.warmup}
+        if parity is not None:
+            line["parity"] = parity
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(size, n_embed)
         if kernels:
