@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void vq_stats_chunk_kernel(const float *__rest
 // One workgroup per code.  A code whose rows span n > 1 chunks has one partial per chunk; a single chain over them would
 // be a latency chain of n dependent L2 round trips (n = 2,048 when every vector of a 32 x 64 x 64 batch picks the same
 // code), so the fold is a fixed two-stage tree instead: CL = 256 / (D/4) interleaved chains (thread (c, q) adds the
-// float4 q of chunks g0 + c, g0 + c + CL, ... in order, 8 loads in flight), then the CL chain sums in order of c.
+// float4 q of chunks g0 + c, g0 + c + CL, ... in order, 16 loads in flight), then the CL chain sums in order of c.
 __global__ __launch_bounds__(256) void vq_stats_fix_kernel(int K, int D, const int *__restrict__ codeoff,
                                                            const float *__restrict__ carry, float *__restrict__ sumsT) {
     __shared__ float4 red[256];
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void vq_stats_fix_kernel(int K, int D, const i
     const int g0 = s / ST_CH, g1 = (e - 1) / ST_CH;
     if (g0 == g1) return;   // the chunk kernel wrote the complete sum
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    constexpr int U = 8;
+    constexpr int U = 16;
     for (int gb = g0 + c; gb <= g1; gb += CL * U) {
         float4 v[U];
 #pragma unroll
