@@ -281,6 +281,8 @@ int vq2_comm_destroy(void);
 /* calibration only: register-resident fp32-MFMA loop (blocks x 256 threads, iters x 32 MFMAs per wave);
  * 2*32*32*2 FLOP per MFMA.  Used by scripts/mfma_peak.py to measure the ceiling the chip sustains. */
 int vq2_debug_mfma_peak(float *scratch, int32_t blocks, int32_t iters, vq2_stream_t stream);
+/* same through v_mfma_f32_16x16x4_f32: iters x 64 MFMAs per wave, 2*16*16*4 FLOP each */
+int vq2_debug_mfma_peak16(float *scratch, int32_t blocks, int32_t iters, vq2_stream_t stream);
 /* diagnostic only: per-phase cycle stamps of the 128x128x32 conv tile into buf[16] (NULL = off) */
 int vq2_debug_set_rb_stamps(unsigned long long *buf); /* same for the fused ResBlock backward kernel: buf[64] */
 int vq2_debug_set_stamps(unsigned long long *buf);

@@ -87,6 +87,7 @@ def _load():
         "vq2_comm_broadcast": (C.c_int, [P, I64, I32, P]),
         "vq2_comm_destroy": (C.c_int, []),
         "vq2_debug_mfma_peak": (C.c_int, [P, I32, I32, P]),
+        "vq2_debug_mfma_peak16": (C.c_int, [P, I32, I32, P]),
         "vq2_debug_set_rb_stamps": (C.c_int, [P]),
         "vq2_debug_set_stamps": (C.c_int, [P]),
     }

@@ -295,6 +295,34 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(float *out, int iters, f
     if (s == 123.456f) out[0] = s;  // keep the loop alive
 }
 
+// the same arithmetic rate through v_mfma_f32_16x16x4_f32 (32 cycles per instruction, half the FLOPs): does the chip
+// hold a different clock for this shape (MI355X_MICROARCH.md, DVFS note 7)?
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void mfma_peak16_kernel(float *out, int iters, float seed) {
+    f32x4v acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    float a = seed + threadIdx.x * 1e-3f, b = seed - threadIdx.x * 2e-3f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+            a += 1e-6f;
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 123.456f) out[0] = s;
+}
+
+extern "C" int vq2_debug_mfma_peak16(float *scratch, int32_t blocks, int32_t iters, vq2_stream_t stream) {
+    VQ2_REQUIRE(scratch && blocks > 0 && iters > 0, "mfma_peak16: bad arguments");
+    hipLaunchKernelGGL(mfma_peak16_kernel, dim3(blocks), dim3(256), 0, to_stream(stream), scratch, iters, 0.5f);
+    return check_launch("mfma_peak16_kernel");
+}
+
 extern "C" int vq2_debug_mfma_peak(float *scratch, int32_t blocks, int32_t iters, vq2_stream_t stream) {
     VQ2_REQUIRE(scratch && blocks > 0 && iters > 0, "mfma_peak: bad arguments");
     hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, to_stream(stream), scratch, iters, 0.5f);
