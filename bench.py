@@ -105,9 +105,13 @@ def main():
     import vqvae2_amd
     # device binding + RCCL group ("nccl" is RCCL on ROCm) from the launcher environment; at world size 1 a group
     # exists only under VQ2_DP_FORCE=1 (exercises the collective path on one GPU)
-    rank, local_rank, world = vqvae2_amd.distributed.bringup("nccl")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # (VQ2_BENCH_BACKEND=gloo + VQ2_SHARE_GPU=1: rehearsal of the N > 1 path with several ranks on ONE GPU, which RCCL
+    #  refuses; used by tests/test_gpu_rccl.py -- the numbers of such a run mean nothing)
+    backend = os.environ.get("VQ2_BENCH_BACKEND", "nccl")
+    rank, local_rank, world = vqvae2_amd.distributed.bringup(backend)
+    dev_index = 0 if os.environ.get("VQ2_SHARE_GPU", "0") != "0" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     from oracle import vqvae_oracle as O
     lib = vqvae2_amd._lib.lib

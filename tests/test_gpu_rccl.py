@@ -25,9 +25,9 @@ def _free_port():
     return p
 
 
-def _torchrun(script_args, extra_env):
+def _torchrun(script_args, extra_env, nproc=1):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port())] + script_args
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
 
@@ -74,3 +74,17 @@ def test_bench_under_torchrun_with_rccl_group():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0
     assert line["collectives"]["backend"] == "nccl" and line["collectives"]["early_tail_buckets"] == 4
+
+
+def test_bench_two_ranks_rehearsal_over_gloo():
+    """The driver's multi-GPU command line (torch.distributed.run --nproc-per-node N bench.py --gpus N) with N = 2
+    ranks sharing the one GPU of the test box over gloo: rank-dependent inputs, the initial broadcast, both buckets,
+    barriers, the MAX-over-ranks timing and the single JSON line of rank 0."""
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "tiny",
+                   "--no-cpu-baseline"], {"VQ2_BENCH_BACKEND": "gloo", "VQ2_SHARE_GPU": "1"}, nproc=2)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0)"
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 8 and line["config"]["parallelism"] == "dp2"
+    assert line["scaling"] == "weak" and line["value"] > 0 and line["collectives"]["early_tail_buckets"] == 4
