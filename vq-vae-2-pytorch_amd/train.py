@@ -44,7 +44,7 @@ class Stage1Trainer:
         if sched == "cycle":  # train_vqvae.py:188-195
             self.scheduler = CycleScheduler(self.optimizer, lr, n_iter=n_iter, momentum=None, warmup_proportion=0.05)
         # this trainer's backward-pass state hangs on ITS parameters (no process-global state)
-        wgrad_stream = torch.cuda.Stream() if os.environ.get("VQ2_WGRAD_STREAM", "0") != "0" else None
+        wgrad_stream = torch.cuda.Stream() if os.environ.get("VQ2_WGRAD_STREAM", "1") != "0" else None
         self.ctx = ops.StepContext(wgrad_stream)
         for p in self.arena.params:
             p._vq2_ctx = self.ctx
