@@ -225,6 +225,11 @@ int vq2_vq_bwd(const float *g_out, int32_t ldg, const float *g_diff, const float
 int vq2_vq_ema_update(float *embed, float *cluster_size, float *embed_avg, const float *counts, const float *sumsT,
                       int32_t D, int32_t K, double decay, double eps, float *scratch /* >= 1 float */,
                       vq2_stream_t stream);
+/* the same update, also leaving embedT / enorm of the UPDATED codebook (what vq2_vq_prepare would compute before
+ * the next forward, bit for bit): one launch less per quantizer and step.  D must divide 256. */
+int vq2_vq_ema_update_prepare(float *embed, float *cluster_size, float *embed_avg, const float *counts,
+                              const float *sumsT, int32_t D, int32_t K, double decay, double eps, float *scratch,
+                              float *embedT, float *enorm, vq2_stream_t stream);
 int vq2_vq_gather(const int64_t *idx, const float *embedT, int64_t M, int32_t D, int32_t K, float *out, int32_t ldo,
                   vq2_stream_t stream);
 
@@ -253,6 +258,10 @@ int vq2_adain_bwd(const float *dy, int32_t lddy, const float *y, int32_t ldy, co
 size_t vq2_mse_workspace_bytes(int64_t numel);
 int vq2_mse_fwd_bwd(const float *a, const float *b, int64_t numel, int64_t denom, const float *gscale, float *loss,
                     float *grad, void *ws, size_t ws_bytes, vq2_stream_t stream);
+/* the whole stage-1 loss in the same two launches: recon = MSE(a, b), total = recon + weight * latent[0]
+ * (train_vqvae.py:83-85), grad = 2*(a-b)/denom */
+int vq2_stage1_loss(const float *a, const float *b, int64_t numel, int64_t denom, const float *latent, float weight,
+                    float *recon, float *total, float *grad, void *ws, size_t ws_bytes, vq2_stream_t stream);
 int vq2_adam_step(float *p, const float *g, float *m, float *v, int64_t n, double lr, double beta1, double beta2,
                   double eps, int32_t step, double grad_scale, vq2_stream_t stream);
 /* dst = a + alpha * b (flat): the 0.25 * latent_loss accumulation and small host-free scalar math */

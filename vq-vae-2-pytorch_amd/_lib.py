@@ -70,12 +70,14 @@ def _load():
         "vq2_vq_loss": (C.c_int, [P, I64, I32, P, P]),
         "vq2_vq_bwd": (C.c_int, [P, I32, P, P, I32, P, P, I64, I32, I32, P, I32, P]),
         "vq2_vq_ema_update": (C.c_int, [P, P, P, P, P, I32, I32, D, D, P, P]),
+        "vq2_vq_ema_update_prepare": (C.c_int, [P, P, P, P, P, I32, I32, D, D, P, P, P, P]),
         "vq2_vq_gather": (C.c_int, [P, P, I64, I32, I32, P, I32, P]),
         "vq2_instnorm_stats": (C.c_int, [P, I32, I32, I64, I32, D, P, P, P]),
         "vq2_adain_fwd": (C.c_int, [P, I32, P, P, P, I32, I64, I32, C.c_int, P, I32, P]),
         "vq2_adain_bwd": (C.c_int, [P, I32, P, I32, P, I32, P, P, P, I32, I64, I32, P, P, I32, P]),
         "vq2_mse_workspace_bytes": (SZ, [I64]),
         "vq2_mse_fwd_bwd": (C.c_int, [P, P, I64, I64, P, P, P, P, SZ, P]),
+        "vq2_stage1_loss": (C.c_int, [P, P, I64, I64, P, F, P, P, P, P, SZ, P]),
         "vq2_adam_step": (C.c_int, [P, P, P, P, I64, D, D, D, D, I32, D, P]),
         "vq2_axpby": (C.c_int, [P, P, F, P, I64, P]),
         "vq2_scale": (C.c_int, [P, P, F, P, I64, P]),

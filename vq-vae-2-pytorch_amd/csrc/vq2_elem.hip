@@ -126,7 +126,10 @@ __global__ __launch_bounds__(256) void mse_partial_kernel(const float *__restric
     if (threadIdx.x == 0) part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
-__global__ void mse_final_kernel(const float *__restrict__ part, int nparts, float denom, float *__restrict__ loss) {
+// latent != null: also total[0] = loss + weight * latent[0], the `recon_loss + 0.25 * latent_loss` of train_vqvae.py:85
+// (same two fp32 operations as the stand-alone axpby launch it replaces)
+__global__ void mse_final_kernel(const float *__restrict__ part, int nparts, float denom, float *__restrict__ loss,
+                                 const float *__restrict__ latent, float weight, float *__restrict__ total) {
     __shared__ float red[256];
     float s = 0.f;
     for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
@@ -136,7 +139,11 @@ __global__ void mse_final_kernel(const float *__restrict__ part, int nparts, flo
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) loss[0] = red[0] / denom;
+    if (threadIdx.x == 0) {
+        const float l = red[0] / denom;
+        loss[0] = l;
+        if (latent) total[0] = l + weight * latent[0];
+    }
 }
 
 // torch.optim.Adam single-tensor math (lerp / addcmul / addcdiv), one pass over a flat arena
@@ -227,8 +234,25 @@ extern "C" int vq2_slice_copy(const float *src, int32_t lds_, float *dst, int32_
 
 extern "C" size_t vq2_mse_workspace_bytes(int64_t numel) { return numel > 0 ? MSE_BLOCKS * sizeof(float) : 0; }
 
+static int mse_impl(const float *a, const float *b, int64_t numel, int64_t denom, const float *gscale, float *loss,
+                    float *grad, const float *latent, float weight, float *total, void *ws, size_t ws_bytes,
+                    vq2_stream_t stream);
+
 extern "C" int vq2_mse_fwd_bwd(const float *a, const float *b, int64_t numel, int64_t denom, const float *gscale,
                                float *loss, float *grad, void *ws, size_t ws_bytes, vq2_stream_t stream) {
+    return mse_impl(a, b, numel, denom, gscale, loss, grad, nullptr, 0.f, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int vq2_stage1_loss(const float *a, const float *b, int64_t numel, int64_t denom, const float *latent,
+                               float weight, float *recon, float *total, float *grad, void *ws, size_t ws_bytes,
+                               vq2_stream_t stream) {
+    VQ2_REQUIRE(latent && total, "stage1_loss: null pointer");
+    return mse_impl(a, b, numel, denom, nullptr, recon, grad, latent, weight, total, ws, ws_bytes, stream);
+}
+
+static int mse_impl(const float *a, const float *b, int64_t numel, int64_t denom, const float *gscale, float *loss,
+                    float *grad, const float *latent, float weight, float *total, void *ws, size_t ws_bytes,
+                    vq2_stream_t stream) {
     VQ2_REQUIRE(a && b && loss && ws && numel > 0 && denom > 0, "mse: bad arguments");
     VQ2_REQUIRE(aligned16(a) && aligned16(b) && (!grad || aligned16(grad)), "mse: pointers must be 16-byte aligned");
     VQ2_REQUIRE(ws_bytes >= MSE_BLOCKS * sizeof(float), "mse: workspace too small");
@@ -238,7 +262,7 @@ extern "C" int vq2_mse_fwd_bwd(const float *a, const float *b, int64_t numel, in
                        gscale, grad, static_cast<float *>(ws));
     if (int e = check_launch("mse_partial_kernel")) return e;
     hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, s, static_cast<const float *>(ws), blocks,
-                       (float)denom, loss);
+                       (float)denom, loss, latent, weight, total);
     return check_launch("mse_final_kernel");
 }
 

@@ -501,20 +501,53 @@ __global__ __launch_bounds__(1024) void vq_ema_counts_kernel(float *__restrict__
 
 // vqvae.py:64, 67-70: embed_avg EMA and the normalised codebook; thread index runs over [k][d] so the
 // transposed statistics are read coalesced
+// PREP (embedT / enorm outputs, 256 % D == 0): the launch also leaves what the NEXT forward's vq2_vq_prepare would
+// compute -- the transposed codebook and ||e_k||^2 summed in vq_prepare_kernel's own order (four chains over
+// d = g, g+4, ..., then (p0+p1)+(p2+p3)), so distances and indices are bit-identical to preparing separately.  A block's
+// 256 threads own 256/D complete codes (256 and the grid stride are multiples of D).
+template <bool PREP>
 __global__ __launch_bounds__(256) void vq_ema_embed_kernel(float *__restrict__ embed, const float *__restrict__ cluster_size,
                                                            float *__restrict__ embed_avg, const float *__restrict__ sumsT,
                                                            int D, int K, float decay, float alpha, float eps, float keps,
-                                                           const float *__restrict__ n_in) {
+                                                           const float *__restrict__ n_in, float *__restrict__ embedT,
+                                                           float *__restrict__ enorm) {
+    __shared__ float e2[256];
+    __shared__ float part[256];
     const float n = n_in[0];
     const float denom = n + keps;
     const int total = D * K;
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
-        const int k = t / D, d = t - k * D;
-        const size_t o = (size_t)d * K + k;
-        const float ea = fmaf(alpha, sumsT[t], embed_avg[o] * decay);
-        embed_avg[o] = ea;
-        const float cs = (cluster_size[k] + eps) / denom * n;
-        embed[o] = ea / cs;
+    const int rounds = (total + gridDim.x * 256 - 1) / (gridDim.x * 256);
+    for (int r = 0; r < rounds; ++r) {
+        const int t = (r * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        const bool tv = t < total;
+        const int k = tv ? t / D : 0, d = tv ? t - k * D : 0;
+        float e = 0.f;
+        if (tv) {
+            const size_t o = (size_t)d * K + k;
+            const float ea = fmaf(alpha, sumsT[t], embed_avg[o] * decay);
+            embed_avg[o] = ea;
+            const float cs = (cluster_size[k] + eps) / denom * n;
+            e = ea / cs;
+            embed[o] = e;
+            if (PREP) embedT[t] = e;
+        }
+        if (PREP) {
+            e2[threadIdx.x] = e * e;
+            __syncthreads();
+            if (tv && d < 4) {
+                float sacc = 0.f;
+                const int base = threadIdx.x - d;
+                for (int dd = d; dd < D; dd += 4) sacc += e2[base + dd];
+                part[threadIdx.x] = sacc;
+            }
+            __syncthreads();
+            if (tv && d == 0) {
+                const float p0 = part[threadIdx.x], p1 = D > 1 ? part[threadIdx.x + 1] : 0.f;
+                const float p2 = D > 2 ? part[threadIdx.x + 2] : 0.f, p3 = D > 3 ? part[threadIdx.x + 3] : 0.f;
+                enorm[k] = (p0 + p1) + (p2 + p3);
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -715,21 +748,42 @@ extern "C" int vq2_vq_bwd(const float *g_out, int32_t ldg, const float *g_diff, 
     return check_launch("vq_bwd_kernel");
 }
 
+static int ema_update_impl(float *embed, float *cluster_size, float *embed_avg, const float *counts, const float *sumsT,
+                           int32_t D, int32_t K, double decay, double eps, float *scratch, float *embedT, float *enorm,
+                           hipStream_t s) {
+    // Python forms (1 - decay) and n_embed * eps in double before the fp32 ops (vqvae.py:62,67)
+    const float alpha = (float)(1.0 - decay);
+    hipLaunchKernelGGL(vq_ema_counts_kernel, dim3(1), dim3(1024), 0, s, cluster_size, counts, K, (float)decay, alpha,
+                       scratch);
+    if (int e = check_launch("vq_ema_counts_kernel")) return e;
+    const int blocks = (D * K + 255) / 256;
+    const dim3 grid(blocks > 1024 ? 1024 : blocks);
+    if (embedT)
+        hipLaunchKernelGGL(vq_ema_embed_kernel<true>, grid, dim3(256), 0, s, embed, cluster_size, embed_avg, sumsT, D, K,
+                           (float)decay, alpha, (float)eps, (float)((double)K * eps), scratch, embedT, enorm);
+    else
+        hipLaunchKernelGGL(vq_ema_embed_kernel<false>, grid, dim3(256), 0, s, embed, cluster_size, embed_avg, sumsT, D, K,
+                           (float)decay, alpha, (float)eps, (float)((double)K * eps), scratch, embedT, enorm);
+    return check_launch("vq_ema_embed_kernel");
+}
+
 extern "C" int vq2_vq_ema_update(float *embed, float *cluster_size, float *embed_avg, const float *counts,
                                  const float *sumsT, int32_t D, int32_t K, double decay, double eps, float *scratch,
                                  vq2_stream_t stream) {
     VQ2_REQUIRE(embed && cluster_size && embed_avg && counts && sumsT && scratch && D > 0 && K > 0,
                 "vq_ema_update: bad arguments");
-    // Python forms (1 - decay) and n_embed * eps in double before the fp32 ops (vqvae.py:62,67)
-    const float alpha = (float)(1.0 - decay);
-    hipStream_t s = to_stream(stream);
-    hipLaunchKernelGGL(vq_ema_counts_kernel, dim3(1), dim3(1024), 0, s, cluster_size, counts, K, (float)decay, alpha,
-                       scratch);
-    if (int e = check_launch("vq_ema_counts_kernel")) return e;
-    const int blocks = (D * K + 255) / 256;
-    hipLaunchKernelGGL(vq_ema_embed_kernel, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, s, embed, cluster_size,
-                       embed_avg, sumsT, D, K, (float)decay, alpha, (float)eps, (float)((double)K * eps), scratch);
-    return check_launch("vq_ema_embed_kernel");
+    return ema_update_impl(embed, cluster_size, embed_avg, counts, sumsT, D, K, decay, eps, scratch, nullptr, nullptr,
+                           to_stream(stream));
+}
+
+extern "C" int vq2_vq_ema_update_prepare(float *embed, float *cluster_size, float *embed_avg, const float *counts,
+                                         const float *sumsT, int32_t D, int32_t K, double decay, double eps,
+                                         float *scratch, float *embedT, float *enorm, vq2_stream_t stream) {
+    VQ2_REQUIRE(embed && cluster_size && embed_avg && counts && sumsT && scratch && embedT && enorm && D > 0 && K > 0,
+                "vq_ema_update_prepare: bad arguments");
+    VQ2_REQUIRE(D <= 256 && 256 % D == 0, "vq_ema_update_prepare: D must divide 256 (D=%d)", D);
+    return ema_update_impl(embed, cluster_size, embed_avg, counts, sumsT, D, K, decay, eps, scratch, embedT, enorm,
+                           to_stream(stream));
 }
 
 extern "C" int vq2_vq_gather(const int64_t *idx, const float *embedT, int64_t M, int32_t D, int32_t K, float *out,

@@ -745,12 +745,14 @@ class QuantizeFn(Function):
     fp32 buffer [counts (K) | sumsT (K*D)] of vqvae.py:55-56 (None in eval mode)."""
 
     @staticmethod
-    def forward(ctx, x, embed, want_stats, stats_buf, out_buf):
+    def forward(ctx, x, embed, want_stats, stats_buf, out_buf, prep=None):
+        """prep: (embedT, enorm) of `embed` if the caller already holds them (Quantize caches what
+        vq2_vq_ema_update_prepare leaves), else they are computed here."""
         x = as_nhwc(x)
         n, h, w, d = x.shape
         k = embed.shape[1]
         m = n * h * w
-        embed_t, enorm = vq_prepare(embed)
+        embed_t, enorm = prep if prep is not None else vq_prepare(embed)
         idx = torch.empty((n, h, w), device=x.device, dtype=torch.int64)
         if out_buf is None:
             out = torch.empty((n, h, w, d), device=x.device, dtype=torch.float32)
@@ -789,7 +791,7 @@ class QuantizeFn(Function):
         x, idx, embed_t = ctx.saved_tensors
         n, h, w, d = x.shape
         if g_out is None and g_diff is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         if g_out is not None:
             g_out = as_nhwc(g_out)
         if g_diff is not None and not g_diff.is_contiguous():
@@ -797,21 +799,28 @@ class QuantizeFn(Function):
         dx = torch.empty((n, h, w, d), device=x.device, dtype=torch.float32)
         check(lib.vq2_vq_bwd(_p(g_out), ld_of(g_out) if g_out is not None else d, _p(g_diff), _p(x), ld_of(x),
                              _p(idx), _p(embed_t), n * h * w, d, ctx.k, _p(dx), d, _stream()), "vq_bwd")
-        return dx, None, None, None, None
+        return dx, None, None, None, None, None
 
 
-def vq_ema_update(embed, cluster_size, embed_avg, stats, decay, eps):
+def vq_ema_update(embed, cluster_size, embed_avg, stats, decay, eps, prep_out=None):
+    """prep_out: (embedT [K,D], enorm [K]) buffers that receive the prepared form of the UPDATED codebook (same launch)."""
     d, k = embed.shape
     counts, sums_t = stats[:k], stats[k:]
     scratch = torch.empty(4, device=embed.device, dtype=torch.float32)
+    if prep_out is not None and 256 % d == 0:
+        check(lib.vq2_vq_ema_update_prepare(_p(embed), _p(cluster_size), _p(embed_avg), _p(counts), _p(sums_t), d, k,
+                                            float(decay), float(eps), _p(scratch), _p(prep_out[0]), _p(prep_out[1]),
+                                            _stream()), "vq_ema_update_prepare")
+        return True
     check(lib.vq2_vq_ema_update(_p(embed), _p(cluster_size), _p(embed_avg), _p(counts), _p(sums_t), d, k,
                                 float(decay), float(eps), _p(scratch), _stream()), "vq_ema_update")
+    return False
 
 
-def vq_gather(idx, embed):
+def vq_gather(idx, embed, prep=None):
     """embed_code (vqvae.py:77-78): idx [...] int64 -> [..., D]."""
     d, k = embed.shape
-    embed_t, _ = vq_prepare(embed)
+    embed_t, _ = prep if prep is not None else vq_prepare(embed)
     idx_c = idx.contiguous()
     m = idx_c.numel()
     out = torch.empty((*idx.shape, d), device=embed.device, dtype=torch.float32)
@@ -865,13 +874,12 @@ def stage1_loss_and_seeds(dec, diff, img, weight, denom):
         raise RuntimeError("stage1_loss_and_seeds: contiguous dec/img and the [1]-shaped latent loss expected")
     n = dc.numel()
     recon = torch.empty((), device=dc.device, dtype=torch.float32)
-    grad = torch.empty_like(dc)
-    ws = torch.empty(lib.vq2_mse_workspace_bytes(n) // 4, device=dc.device, dtype=torch.float32)
-    check(lib.vq2_mse_fwd_bwd(_p(dc), _p(ic), n, int(denom), None, _p(recon), _p(grad), _p(ws), ws.numel() * 4,
-                              _stream()), "mse_fwd_bwd")
-    latent = diff.detach().reshape(())
     loss = torch.empty((), device=dc.device, dtype=torch.float32)
-    check(lib.vq2_axpby(_p(recon), _p(latent), float(weight), _p(loss), 1, _stream()), "axpby")
+    grad = torch.empty_like(dc)
+    latent = diff.detach().reshape(())
+    ws = torch.empty(lib.vq2_mse_workspace_bytes(n) // 4, device=dc.device, dtype=torch.float32)
+    check(lib.vq2_stage1_loss(_p(dc), _p(ic), n, int(denom), _p(latent), float(weight), _p(recon), _p(loss), _p(grad),
+                              _p(ws), ws.numel() * 4, _stream()), "stage1_loss")
     key = (dc.device, float(weight), tuple(diff.shape))
     seed = _DIFF_SEEDS.get(key)
     if seed is None:

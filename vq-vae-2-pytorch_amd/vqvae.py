@@ -113,6 +113,28 @@ class Quantize(nn.Module):
         # set by Stage1Trainer: EMA statistics go to a slice of the packed all-reduce buffer and the
         # update is applied after the collective (legal: the output uses the pre-update codebook)
         self.deferred_stats = None
+        # prepared form of the codebook (embedT [K,D], ||e_k||^2 [K]) left by the EMA update's own launch; valid while
+        # (storage, tensor version, number of raw-pointer updates) of `embed` are the ones it was made from
+        self._prep = None
+        self._prep_key = None
+        self._raw_updates = 0
+
+    def _embed_key(self):
+        return (self.embed.data_ptr(), self.embed._version, self._raw_updates, self.embed.device)
+
+    def _prepared(self):
+        if self._prep is not None and self._prep_key == self._embed_key():
+            return self._prep
+        return None
+
+    def _ema_update(self, stats):
+        # FRESH buffers every time: the previous pair may still be referenced by the autograd graph of the forward that
+        # searched the pre-update codebook (the drop-in path updates inside forward, before backward reads embedT)
+        self._prep = (torch.empty((self.n_embed, self.dim), device=self.embed.device, dtype=torch.float32),
+                      torch.empty(self.n_embed, device=self.embed.device, dtype=torch.float32))
+        fused = ops.vq_ema_update(self.embed, self.cluster_size, self.embed_avg, stats, self.decay, self.eps, self._prep)
+        self._raw_updates += 1       # the kernels write through raw pointers: tensor._version does not move
+        self._prep_key = self._embed_key() if fused else None
 
     def forward(self, input, _out=None):
         """input [B,H,W,dim] -> (quantize [B,H,W,dim], diff 0-dim, embed_ind [B,H,W] int64)."""
@@ -120,20 +142,20 @@ class Quantize(nn.Module):
             raise RuntimeError(f"Quantize: last dim {input.shape[-1]} != {self.dim}")
         x = input if input.dim() == 4 else input.reshape(-1, 1, 1, self.dim)
         want = self.training
-        out, diff, ind, stats = ops.QuantizeFn.apply(x, self.embed, want, self.deferred_stats, _out)
+        out, diff, ind, stats = ops.QuantizeFn.apply(x, self.embed, want, self.deferred_stats, _out, self._prepared())
         if want and self.deferred_stats is None:
             dist_fn.all_reduce(stats)  # counts and sums in ONE collective (vqvae.py:58-59 issues two)
-            ops.vq_ema_update(self.embed, self.cluster_size, self.embed_avg, stats, self.decay, self.eps)
+            self._ema_update(stats)
         if input.dim() != 4:
             out = out.reshape(input.shape)
             ind = ind.reshape(input.shape[:-1])
         return out, diff, ind
 
     def apply_deferred_update(self):
-        ops.vq_ema_update(self.embed, self.cluster_size, self.embed_avg, self.deferred_stats, self.decay, self.eps)
+        self._ema_update(self.deferred_stats)
 
     def embed_code(self, embed_id):
-        return ops.vq_gather(embed_id, self.embed)
+        return ops.vq_gather(embed_id, self.embed, self._prepared())
 
 
 class ResBlock(nn.Module):
