@@ -42,7 +42,6 @@ struct ConvGemmParams {
     int relu_in, relu_out;
     int mask_after;       // apply the mask to (acc + residual) instead of to acc alone
     int nbias;            // bias has nbias entries (real output channels)
-    int tap_inner;        // depth order of the uniform-k tiles: 1 = taps innermost (see conv_gemm_fast_kernel)
     int c4_tpw;           // conv_k4s2_c4_kernel: tiles per workgroup
     int ci_real;          // real input channels (<= Ci; the rest are zero padding), 0 = Ci
     double flops, bytes;  // algorithmic work of this launch (for the profiler only)
@@ -310,7 +309,7 @@ __device__ __forceinline__ float4 as_f4(u32x4 v) {
 // per-thread (kh, kw) counter) -- all 1,024 tiles of a 64x64-resolution layer are then resident at once: ONE
 // round, so one exposed prologue and one epilogue burst per launch instead of two.
 // UNI (Ci % BK == 0, K % BK == 0: every layer but the 3-channel ones): see the scalar k tracking below.
-template <int WAVES_M, int WAVES_N, int MT, int NT, int BK, bool PIPE, bool RELU_IN, bool OCC4 = false, bool UNI = OCC4>
+template <int WAVES_M, int WAVES_N, int MT, int NT, int BK, bool PIPE, bool RELU_IN, bool OCC4 = false, bool UNI = OCC4, bool TAPIN = false>
 __global__ __launch_bounds__(256, OCC4 ? 4 : ((MT * NT == 4) ? (BK == 16 ? 3 : 2) : 1)) void conv_gemm_fast_kernel(const ConvGemmParams P) {
     constexpr int LDK = BK + 4;
     constexpr int BM = WAVES_M * MT * 32;
@@ -454,7 +453,7 @@ __global__ __launch_bounds__(256, OCC4 ? 4 : ((MT * NT == 4) ? (BK == 16 ? 3 : 2
             // for a 67 MB input).  With the TAPS innermost the nine shifted reads of one BK-channel block follow each
             // other directly (23 KB of whole lines per workgroup, ~2 MB of distinct lines per XCD): most are cache hits.
             // The sum is the same set of products in another order (the panel offset of a chunk is still (tap*Ci + cb)).
-            if (P.tap_inner) {   // (32-channel block, tap, channel): the block size is fixed so that every tile shape (BK 16
+            if constexpr (TAPIN) {   // (32-channel block, tap, channel): the block size is fixed so that every tile shape (BK 16
                 u_cb += BK;      // or 32) adds the products in the SAME order -- results do not depend on the tile choice
                 if ((u_cb & 31) == 0) {
                     u_cb -= 32;
@@ -634,9 +633,13 @@ static int launch_conv_gemm_fast(const ConvGemmParams &P, hipStream_t s) {
     const long gib = 1L << 30;
     const bool small = (long)P.N * P.H * P.W * P.ldx * 4 < gib && (long)P.Co * P.K * P.phases * 4 < gib;
     const bool uni = small && (OCC4 || (P.Ci % BK == 0 && P.K % BK == 0));
-    auto kern = P.relu_in ? (uni ? conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, true, true, OCC4, true>
+    static const int tapin = tune("VQ2_TAPIN", 1);
+    const bool tap_inner = uni && tapin && P.KH * P.KW > 1 && P.Ci > 32 && P.Ci % 32 == 0;
+    auto kern = P.relu_in ? (uni ? (tap_inner ? conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, true, true, OCC4, true, true>
+                                              : conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, true, true, OCC4, true, false>)
                                  : conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, true, true, OCC4, OCC4>)
-                          : (uni ? conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, true, false, OCC4, true>
+                          : (uni ? (tap_inner ? conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, true, false, OCC4, true, true>
+                                              : conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, true, false, OCC4, true, false>)
                                  : conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, true, false, OCC4, OCC4>);
     allow_big_lds(kern, lds);
     dim3 grid(nwg);
@@ -645,10 +648,7 @@ static int launch_conv_gemm_fast(const ConvGemmParams &P, hipStream_t s) {
         name = prof_label("conv_gemm<%dx%dx%d>|M=%d,N=%d,K=%d,k%d,s%d,ph%d", BM, BN, BK, P.M, P.Co, P.K, P.KH, P.stride,
                           P.phases);
     ProfScope prof(name, P.flops, P.bytes, s, BM == 128 && BN == 128);
-    static const int tapin = tune("VQ2_TAPIN", 1);
-    ConvGemmParams Q = P;
-    Q.tap_inner = (uni && tapin && P.KH * P.KW > 1 && P.Ci > 32 && P.Ci % 32 == 0) ? 1 : 0;
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, Q);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, P);
     return check_launch("conv_gemm_fast_kernel");
 }
 
