@@ -13,7 +13,7 @@ for f in vq2_conv vq2_wgrad vq2_vq vq2_elem vq2_resblock vq2_norm; do
     # tests/test_host_cpu.py::test_hot_kernels_do_not_spill reads it (a spilled register in a conv tile cost 3 % of
     # the step in round 2 and no functional test could see it)
     ( $HIPCC $FLAGS -Rpass-analysis=kernel-resource-usage -c "$HERE/$f.hip" -o "$HERE/_obj/$f.o" ${VQ2_EXTRA_FLAGS:-} \
-        2> "$HERE/_obj/$f.res"; rc=$?; grep -v "remark:" "$HERE/_obj/$f.res" >&2 || true; exit $rc ) &
+        2> "$HERE/_obj/$f.res"; rc=$?; grep -E -A4 "(error|warning):" "$HERE/_obj/$f.res" >&2 || true; exit $rc ) &
     pids+=($!)
   fi
 done
