@@ -20,7 +20,8 @@ import vqvae as ref  # noqa: E402  (the reference module)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import rng  # noqa: E402
 from oracle import vqvae_oracle as O  # noqa: E402
-from oracle.make_golden_cases import (BLOCK_CASES, CONV_FLAVOURS, DEEP_ADAIN_CASES, DEEP_CONV_FLAVOURS,  # noqa: E402
+from oracle.make_golden_cases import (BLOCK_CASES, CONV_FLAVOURS, DEEP_ADAIN_CASES, DEEP_BLOCK_CASES,  # noqa: E402
+                                      DEEP_CONV_FLAVOURS,
                                       DEEP_EMBED_SCALE, DEEP_GAIN, DEEP_SEED, SCHED_CASES, SEED, block_state, conv_inputs,
                                       quantize_inputs, thin)
 
@@ -249,6 +250,28 @@ def gen_deep():
         y.backward(t(rng.normal(DEEP_SEED, f"{tag}.gy", (nb, c, h, w))))
         d.update({f"{tag}.y": n(y), f"{tag}.gx": n(x.grad), f"{tag}.gs": n(s.grad), f"{tag}.gw": thin(n(m.fc.weight.grad)),
                   f"{tag}.gb": n(m.fc.bias.grad)})
+    # --- Encoder / Decoder at the strides VQVAE_Deep does not use itself
+    for tag, kind, args, xs in DEEP_BLOCK_CASES:
+        m = refd.Encoder(*args) if kind == "encoder" else refd.Decoder(*args)
+        sd = m.state_dict()
+        for k in sd:    # deterministic weights from the counter RNG, same rule as the test side (deep_block_state)
+            shape = tuple(sd[k].shape)
+            fan = int(np.prod(shape[1:])) if len(shape) > 1 else 16
+            sd[k] = t((rng.uniform(DEEP_SEED, f"{tag}.{k}", shape, -1, 1) / np.sqrt(fan)).astype(np.float32))
+        m.load_state_dict(sd)
+        x = t(rng.normal(DEEP_SEED, f"{tag}.x", xs)).requires_grad_(True)
+        styled = kind == "decoder" and args[3] > 1
+        sty = t(rng.normal(DEEP_SEED, f"{tag}.s", (xs[0], args[3]))).requires_grad_(True) if styled else None
+        y = m(x, sty) if styled else m(x)
+        y.backward(t(rng.normal(DEEP_SEED, f"{tag}.gy", tuple(y.shape))))
+        d[f"{tag}.keys"] = np.array(list(sd.keys()))
+        d[f"{tag}.y"] = n(y)
+        d[f"{tag}.gx"] = n(x.grad)
+        if styled:
+            d[f"{tag}.gs"] = n(sty.grad)
+        for k, p_ in m.named_parameters():
+            if p_.grad is not None:
+                d[f"{tag}.g.{k}"] = n(p_.grad)
     # --- the tiny model
     cfg = OD.DEEP_TINY
     m = refd.VQVAE_Deep(channel=cfg.channel, n_res_block=cfg.n_res_block, n_res_channel=cfg.n_res_channel,

@@ -125,3 +125,12 @@ def thin(a, limit=65536):
     flat = np.asarray(a).reshape(-1)
     k = max(1, flat.size // limit)
     return flat[::k].copy() if k > 1 else np.asarray(a)
+
+# Encoder / Decoder geometries of vqvae_deep.py that VQVAE_Deep itself does not use (strides 8 and 4; a styled decoder
+# at stride 4): tag, kind, ctor args in the reference's order, input shape
+DEEP_BLOCK_CASES = [
+    ("denc8", "encoder", (3, 16, 1, 8, 8), (2, 3, 32, 32)),
+    ("denc4", "encoder", (4, 16, 0, 8, 4), (1, 4, 16, 16)),
+    ("ddec8", "decoder", (16, 3, 16, -1, 1, 8, 8), (2, 16, 2, 2)),
+    ("ddec4s", "decoder", (8, 4, 16, 12, 2, 8, 4), (2, 8, 4, 4)),      # AdaIN blocks, style_dim 12
+]

@@ -172,3 +172,35 @@ def test_default_deep_model_runs_one_step(amd):
     close(loss, F.mse_loss(ref[0], img) + 0.25 * ref[1].mean(), rtol=2e-3)
     close(dec, ref[0], rtol=5e-3, atol=5e-3)
     assert all(torch.isfinite(p).all() for p in m.parameters())
+
+
+def test_deep_encoder_decoder_other_strides(amd, golden):
+    """vqvae_deep.Encoder / Decoder at strides 8 and 4 and a styled stride-4 decoder (VQVAE_Deep itself wires 6 and 2):
+    outputs, input / style gradients and every parameter gradient against the reference's."""
+    from oracle.make_golden_cases import DEEP_BLOCK_CASES
+    from vqvae2_amd import vqvae_deep
+    g = golden("deep")
+    for tag, kind, args, xs in DEEP_BLOCK_CASES:
+        m = vqvae_deep.Encoder(*args) if kind == "encoder" else vqvae_deep.Decoder(*args)
+        sd = m.state_dict()
+        assert list(sd.keys()) == [str(k) for k in g[f"{tag}.keys"]], tag
+        for k in sd:
+            shape = tuple(sd[k].shape)
+            fan = int(np.prod(shape[1:])) if len(shape) > 1 else 16
+            sd[k] = t((rng.uniform(DEEP_SEED, f"{tag}.{k}", shape, -1, 1) / np.sqrt(fan)).astype(np.float32))
+        m.load_state_dict(sd)
+        m.to(DEV)
+        x = t(rng.normal(DEEP_SEED, f"{tag}.x", xs)).to(DEV).requires_grad_(True)
+        styled = kind == "decoder" and args[3] > 1
+        sty = t(rng.normal(DEEP_SEED, f"{tag}.s", (xs[0], args[3]))).to(DEV).requires_grad_(True) if styled else None
+        y = m(x, sty) if styled else m(x)
+        close(y, g[f"{tag}.y"], what=f"{tag}.y")
+        y.backward(t(rng.normal(DEEP_SEED, f"{tag}.gy", tuple(y.shape))).to(DEV))
+        close(x.grad, g[f"{tag}.gx"], rtol=5e-4, atol=5e-5, what=f"{tag}.gx")
+        if styled:
+            close(sty.grad, g[f"{tag}.gs"], rtol=5e-4, atol=5e-5, what=f"{tag}.gs")
+        for k, p in m.named_parameters():
+            if f"{tag}.g.{k}" in g.files:
+                close(p.grad, g[f"{tag}.g.{k}"], rtol=1e-3, atol=1e-4, what=f"{tag}.g.{k}")
+            else:
+                assert p.grad is None, f"{tag}.{k}"
