@@ -73,9 +73,11 @@ class Stage1Trainer:
         self._bucket_sent = False
         self.early_buckets = 0      # steps in which the tail bucket went out from the backward hook
         split = getattr(model, "quantize_conv_b", None)
-        if self.dp and split is not None and os.environ.get("VQ2_DP_OVERLAP", "1") != "0":
+        self.early_flush = os.environ.get("VQ2_EARLY_FLUSH", "1") != "0" and self.ctx.stream is not None
+        if split is not None and (self.early_flush or (self.dp and os.environ.get("VQ2_DP_OVERLAP", "1") != "0")):
             first = self.arena.offset[id(split.weight)]
-            self.split_off = self.arena.n_extra + first
+            if self.dp and os.environ.get("VQ2_DP_OVERLAP", "1") != "0":
+                self.split_off = self.arena.n_extra + first
             self.tail_params = [p for p in self.arena.params if self.arena.offset[id(p)] >= first]
             split.weight.register_post_accumulate_grad_hook(self._late_grad_ready)
             split.bias.register_post_accumulate_grad_hook(self._late_grad_ready)
@@ -101,10 +103,21 @@ class Stage1Trainer:
         # keep everything for the single all-reduce after backward.
         if not all(p.grad is not None and p.grad.data_ptr() == p._vq2_grad.data_ptr() for p in self.tail_params):
             return
-        if self.ctx.stream is not None:
-            torch.cuda.current_stream().wait_stream(self.ctx.stream)
-        self.ctx.batch.flush()                      # reduce the split-K slabs produced so far into the arena
-        ev = torch.cuda.current_stream().record_event()
+        # The decoder-side split-K slabs (most of the 546 MB) are reduced into the arena NOW, on the side stream when
+        # there is one, beside the encoder's matrix-bound backward launches -- instead of in one HBM-bound pass after
+        # backward; data parallel: that slice of the gradient buffer then goes out while the encoder back-propagates.
+        side = self.ctx.stream
+        if side is not None:
+            side.wait_event(torch.cuda.current_stream().record_event())
+            with torch.cuda.stream(side):
+                self.ctx.batch.flush()
+                ev = side.record_event()
+        else:
+            self.ctx.batch.flush()
+            ev = torch.cuda.current_stream().record_event()
+        if self.split_off is None:       # single GPU: nothing to send
+            self._bucket_sent = True
+            return
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(ev)
             self.comm.all_reduce(self.arena.flat_g[self.split_off:])
