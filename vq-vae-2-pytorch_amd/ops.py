@@ -745,9 +745,12 @@ class QuantizeFn(Function):
     fp32 buffer [counts (K) | sumsT (K*D)] of vqvae.py:55-56 (None in eval mode)."""
 
     @staticmethod
-    def forward(ctx, x, embed, want_stats, stats_buf, out_buf, prep=None):
+    def forward(ctx, x, embed, want_stats, stats_buf, out_buf, prep=None, stats_stream=None):
         """prep: (embedT, enorm) of `embed` if the caller already holds them (Quantize caches what
-        vq2_vq_ema_update_prepare leaves), else they are computed here."""
+        vq2_vq_ema_update_prepare leaves), else they are computed here.
+        stats_stream: side stream for the EMA statistics when their consumer is far away (Stage1Trainer applies the
+        EMA update after backward): five small latency-bound launches that then run beside the matrix-bound
+        forward / backward kernels instead of between them.  The caller joins the stream before it reads stats_buf."""
         x = as_nhwc(x)
         n, h, w, d = x.shape
         k = embed.shape[1]
@@ -774,8 +777,16 @@ class QuantizeFn(Function):
             # every element of stats is written (deterministic sort + ordered sums, no atomics, no zeroing)
             nbytes = lib.vq2_vq_stats_workspace_bytes(m, d, k)
             ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.int32)
-            check(lib.vq2_vq_stats(_p(x), ld_of(x), _p(idx), m, d, k, _p(stats[:k]), _p(stats[k:]), _p(ws), nbytes,
-                                   _stream()), "vq_stats")
+            if stats_stream is not None and stats_buf is not None:
+                stats_stream.wait_event(torch.cuda.current_stream().record_event())
+                with torch.cuda.stream(stats_stream):
+                    check(lib.vq2_vq_stats(_p(x), ld_of(x), _p(idx), m, d, k, _p(stats[:k]), _p(stats[k:]), _p(ws), nbytes,
+                                           _stream()), "vq_stats")
+                for tns in (x, idx, ws):
+                    tns.record_stream(stats_stream)
+            else:
+                check(lib.vq2_vq_stats(_p(x), ld_of(x), _p(idx), m, d, k, _p(stats[:k]), _p(stats[k:]), _p(ws), nbytes,
+                                       _stream()), "vq_stats")
         diff = torch.empty((), device=x.device, dtype=torch.float32)
         check(lib.vq2_vq_loss(_p(part), m, d, _p(diff), _stream()), "vq_loss")
         ctx.save_for_backward(x, idx, embed_t)
@@ -791,7 +802,7 @@ class QuantizeFn(Function):
         x, idx, embed_t = ctx.saved_tensors
         n, h, w, d = x.shape
         if g_out is None and g_diff is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         if g_out is not None:
             g_out = as_nhwc(g_out)
         if g_diff is not None and not g_diff.is_contiguous():
@@ -799,7 +810,7 @@ class QuantizeFn(Function):
         dx = torch.empty((n, h, w, d), device=x.device, dtype=torch.float32)
         check(lib.vq2_vq_bwd(_p(g_out), ld_of(g_out) if g_out is not None else d, _p(g_diff), _p(x), ld_of(x),
                              _p(idx), _p(embed_t), n * h * w, d, ctx.k, _p(dx), d, _stream()), "vq_bwd")
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
 def vq_ema_update(embed, cluster_size, embed_avg, stats, decay, eps, prep_out=None):

@@ -48,6 +48,9 @@ class Stage1Trainer:
         self.ctx = ops.StepContext(wgrad_stream)
         for p in self.arena.params:
             p._vq2_ctx = self.ctx
+        if os.environ.get("VQ2_STATS_STREAM", "1") != "0":
+            for q in self.quantizers:      # the EMA statistics are consumed after backward: off the main stream
+                q.stats_stream = wgrad_stream
         # every weight panel (forward and data-gradient layouts) re-packed by one launch per step
         layers = []
         for name, mod in model.named_modules():

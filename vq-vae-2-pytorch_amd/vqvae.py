@@ -113,6 +113,7 @@ class Quantize(nn.Module):
         # set by Stage1Trainer: EMA statistics go to a slice of the packed all-reduce buffer and the
         # update is applied after the collective (legal: the output uses the pre-update codebook)
         self.deferred_stats = None
+        self.stats_stream = None     # with deferred_stats: side stream the statistics kernels may run on (see QuantizeFn)
         # prepared form of the codebook (embedT [K,D], ||e_k||^2 [K]) left by the EMA update's own launch; valid while
         # (storage, tensor version, number of raw-pointer updates) of `embed` are the ones it was made from
         self._prep = None
@@ -142,7 +143,8 @@ class Quantize(nn.Module):
             raise RuntimeError(f"Quantize: last dim {input.shape[-1]} != {self.dim}")
         x = input if input.dim() == 4 else input.reshape(-1, 1, 1, self.dim)
         want = self.training
-        out, diff, ind, stats = ops.QuantizeFn.apply(x, self.embed, want, self.deferred_stats, _out, self._prepared())
+        out, diff, ind, stats = ops.QuantizeFn.apply(x, self.embed, want, self.deferred_stats, _out, self._prepared(),
+                                                      self.stats_stream if self.deferred_stats is not None else None)
         if want and self.deferred_stats is None:
             dist_fn.all_reduce(stats)  # counts and sums in ONE collective (vqvae.py:58-59 issues two)
             self._ema_update(stats)
