@@ -25,23 +25,33 @@ from vqvae2_amd import codes  # noqa: E402
 IMG_EXT = (".png", ".jpg", ".jpeg", ".bmp", ".webp")
 
 
+def resize_crop_box(w, h, size):
+    """((new_w, new_h), (left, top, right, bottom)) of transforms.Resize(size) followed by transforms.CenterCrop(size)
+    (extract_code.py:48-51) with torchvision's own integer rules: the short side becomes `size`, the long side is
+    TRUNCATED int(size * long / short); the crop offsets are int(round((dim - size) / 2.0))."""
+    if w <= h:
+        nw, nh = size, int(size * h / w)
+    else:
+        nw, nh = int(size * w / h), size
+    left, top = int(round((nw - size) / 2.0)), int(round((nh - size) / 2.0))
+    return (nw, nh), (left, top, left + size, top + size)
+
+
 def image_batches(path, size, batch=128):
-    """ImageFolder order (sorted classes, sorted files); filename = class/file (dataset.py:14-22)."""
+    """ImageFolder order (sorted classes, sorted walk, sorted files); filename = immediate parent directory / file
+    (dataset.py:14-22 takes the LAST directory component, which differs from the class for nested folders)."""
     from PIL import Image
     files = []
     for cls in sorted(d for d in os.listdir(path) if os.path.isdir(os.path.join(path, d))):
-        for root, _, names in sorted(os.walk(os.path.join(path, cls))):
-            files += [(os.path.join(root, n), os.path.join(cls, n)) for n in sorted(names) if n.lower().endswith(IMG_EXT)]
+        for root, _, names in sorted(os.walk(os.path.join(path, cls), followlinks=True)):
+            files += [(os.path.join(root, n), os.path.join(os.path.basename(root), n))
+                      for n in sorted(names) if n.lower().endswith(IMG_EXT)]
     for i in range(0, len(files), batch):
         arrs = []
         for full, _ in files[i:i + batch]:
             im = Image.open(full).convert("RGB")
-            w, h = im.size
-            s = size / min(w, h)                                                     # transforms.Resize(size)
-            im = im.resize((max(size, round(w * s)), max(size, round(h * s))), Image.BILINEAR)
-            w, h = im.size
-            left, top = (w - size) // 2, (h - size) // 2                            # transforms.CenterCrop(size)
-            a = np.asarray(im.crop((left, top, left + size, top + size)), np.float32) / 255.0
+            new_size, box = resize_crop_box(*im.size, size)
+            a = np.asarray(im.resize(new_size, Image.BILINEAR).crop(box), np.float32) / 255.0
             arrs.append((a.transpose(2, 0, 1) - 0.5) / 0.5)                          # ToTensor + Normalize(0.5, 0.5)
         yield torch.from_numpy(np.stack(arrs)), [name for _, name in files[i:i + batch]]
 

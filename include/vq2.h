@@ -39,6 +39,13 @@ extern "C" {
 
 typedef void *vq2_stream_t;
 
+/* ABI revision of THIS header.  It moves whenever an entry point changes its argument list or the meaning of an
+ * argument / workspace (revision 2: vq2_vq_fwd lost its counts/sumsT arguments and vq2_vq_fwd_workspace_floats
+ * went from (M) to (M, D, K); revision 3: round-3 additions, see INTEGRATION.md "ABI history").  vq2_version()
+ * returns the revision the LIBRARY was built from: a host must refuse to run when the two differ (a mismatched
+ * workspace size would let a kernel write past the caller's buffer). */
+#define VQ2_API_VERSION 3
+
 int vq2_version(void);
 const char *vq2_last_error(void);
 

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(amd):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in vq2.h but not exported"
     assert declared == set(amd._lib.EXPORTS), declared ^ set(amd._lib.EXPORTS)
-    assert lib.vq2_version() >= 1
+    assert lib.vq2_version() == amd._lib.API_VERSION == int(re.search(r"#define\s+VQ2_API_VERSION\s+(\d+)", hdr).group(1))
 
 
 def test_hot_kernels_do_not_spill():
@@ -125,9 +125,10 @@ def test_cycle_scheduler_matches_reference_golden(amd, golden):
             lrs.append(lr)
             moms.append(np.nan if mom is None else mom)
             assert opt.param_groups[0]["lr"] == lr
-            np.testing.assert_allclose(opt.param_groups[0]["betas"][0], g[f"{tag}.group_beta1"][i], rtol=1e-12)
-        np.testing.assert_allclose(lrs, g[f"{tag}.lr"], rtol=1e-10, atol=0)
-        np.testing.assert_allclose(moms, g[f"{tag}.momentum"], rtol=1e-12, equal_nan=True)
+            assert opt.param_groups[0]["betas"][0] == g[f"{tag}.group_beta1"][i]
+        # bit parity: every segment is evaluated with the reference's own expressions (scheduler.py:221-228)
+        assert np.array_equal(np.asarray(lrs), g[f"{tag}.lr"]), tag
+        assert np.array_equal(np.asarray(moms), g[f"{tag}.momentum"], equal_nan=True), tag
     tag, kw, steps = SCHED_CASES[0]
     o = O.CycleSchedule(kw["lr_max"], kw["n_iter"], warmup_proportion=kw["warmup_proportion"])
     np.testing.assert_allclose([o.step() for _ in range(steps)], g[f"{tag}.lr"], rtol=1e-12, atol=0)
@@ -138,7 +139,7 @@ def test_cycle_scheduler_matches_reference_golden(amd, golden):
         a.step()
     b = amd.CycleScheduler(opt, **kw)
     b.load_state_dict(a.state_dict())
-    np.testing.assert_allclose([b.step()[0] for _ in range(400)], g[f"{tag}.lr"][123:523], rtol=1e-10, atol=0)
+    assert np.array_equal(np.asarray([b.step()[0] for _ in range(400)]), g[f"{tag}.lr"][123:523])
     with pytest.raises(ZeroDivisionError):      # the reference divides by an empty warm-up phase on its first step
         amd.CycleScheduler(opt, 1e-3, n_iter=10, warmup_proportion=0.05).step()
 
@@ -176,6 +177,43 @@ def test_code_rows_are_the_reference_pickles(amd, tmp_path):
     assert name == "b/2.png" and torch.equal(t2, torch.from_numpy(top + 2)) and torch.equal(b2, torch.from_numpy(bottom + 2))
     with codes.CodeStore(path, "r") as st:
         assert st.get(b"1") == codes.code_row_bytes(top + 1, bottom + 1, "a/1.png") and st.get(b"length") == b"3"
+
+
+def test_code_row_loader_refuses_foreign_globals(amd, tmp_path):
+    """A row blob that names anything but dataset.CodeRow / numpy's array rebuild helpers must raise, not run."""
+    import pickle
+    import numpy as np
+    from vqvae2_amd import codes
+    marker = tmp_path / "ran"
+
+    class Evil:
+        def __reduce__(self):
+            return (open, (str(marker), "w"))
+    with pytest.raises(pickle.UnpicklingError):
+        codes.load_code_row(pickle.dumps(Evil()))
+    assert not marker.exists()
+    with pytest.raises(pickle.UnpicklingError):      # right container, wrong payload types
+        codes.load_code_row(pickle.dumps(("top", "bottom", "name")))
+    with pytest.raises(pickle.UnpicklingError):      # object arrays could smuggle arbitrary pickles
+        codes.load_code_row(codes.code_row_bytes(np.array([{"a": 1}], dtype=object), np.zeros(2, np.int64), "x"))
+    t, b, n = codes.load_code_row(codes.code_row_bytes(np.arange(4), np.arange(6), "k/x.png"))
+    assert n == "k/x.png" and t.tolist() == [0, 1, 2, 3] and b.dtype == np.int64
+
+
+def test_extract_code_preprocessing_uses_torchvision_integer_rules(amd):
+    """transforms.Resize(size) truncates the long side (int(size * long / short)) and transforms.CenterCrop(size)
+    offsets are int(round((dim - size) / 2.0)) -- hand-computed boxes for odd-sized images (extract_code.py:46-51;
+    torchvision itself is not importable here, so these are the formulas' values, not a captured run)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("extract_code_example", os.path.join(ROOT, "examples", "extract_code.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    box = mod.resize_crop_box
+    assert box(301, 200, 64) == ((96, 64), (16, 0, 80, 64))           # 64*301/200 = 96.32 -> 96
+    assert box(203, 100, 33) == ((66, 33), (16, 0, 49, 33))           # 66.99 truncates to 66 (rounding would say 67)
+    assert box(207, 100, 33) == ((68, 33), (18, 0, 51, 33))           # (68-33)/2 = 17.5 -> round -> 18 (floor: 17)
+    assert box(100, 206, 33) == ((33, 67), (0, 17, 33, 50))           # 67.98 truncates to 67
+    assert box(256, 256, 256) == ((256, 256), (0, 0, 256, 256))
 
 
 def test_launch_spawns_ranks_and_joins_the_group(amd, tmp_path):

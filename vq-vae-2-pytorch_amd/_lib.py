@@ -100,7 +100,19 @@ def _load():
     return lib, tuple(sig.keys())
 
 
+def _header_api_version():
+    """VQ2_API_VERSION of include/vq2.h (the header this binding was written against)."""
+    import re
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "vq2.h")
+    with open(hdr) as f:
+        return int(re.search(r"#define\s+VQ2_API_VERSION\s+(\d+)", f.read()).group(1))
+
+
 lib, EXPORTS = _load()
+API_VERSION = _header_api_version()
+if lib.vq2_version() != API_VERSION:
+    raise ImportError(f"{LIB_PATH} implements ABI revision {lib.vq2_version()} but include/vq2.h declares "
+                      f"{API_VERSION}: rebuild the library (vq-vae-2-pytorch_amd/csrc/build.sh)")
 
 
 def check(code, what=""):

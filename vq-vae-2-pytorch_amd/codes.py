@@ -57,10 +57,34 @@ def code_row_bytes(top, bottom, filename):
         return pickle.dumps(row(top=top, bottom=bottom, filename=filename))
 
 
+_ROW = collections.namedtuple("CodeRow", _FIELDS)
+
+# the only globals a row pickle may reference: the row type itself and what numpy needs to rebuild an ndarray
+_ALLOWED_GLOBALS = {("dataset", "CodeRow")} | {
+    (mod, name) for mod in ("numpy.core.multiarray", "numpy._core.multiarray") for name in ("_reconstruct",)
+} | {("numpy", "ndarray"), ("numpy", "dtype")}
+
+
+class _RowUnpickler(pickle.Unpickler):
+    """A code store may come from elsewhere (including one written by other tooling): rows hold a namedtuple of two
+    int64 ndarrays and a str, so nothing else is allowed to resolve -- a blob that names any other global raises
+    instead of importing / calling it."""
+
+    def find_class(self, module, name):
+        if (module, name) not in _ALLOWED_GLOBALS:
+            raise pickle.UnpicklingError(f"code row refers to {module}.{name}: not a CodeRow of numpy arrays")
+        if (module, name) == ("dataset", "CodeRow"):
+            return _ROW
+        return super().find_class(module, name)
+
+
 def load_code_row(blob):
-    """(top, bottom, filename) from a row written by the reference or by code_row_bytes."""
-    with _code_row_class():
-        r = pickle.loads(blob)
+    """(top, bottom, filename) from a row written by the reference or by code_row_bytes (restricted unpickling)."""
+    import io
+    r = _RowUnpickler(io.BytesIO(blob)).load()
+    if not (isinstance(r, _ROW) and isinstance(r.top, np.ndarray) and isinstance(r.bottom, np.ndarray)
+            and isinstance(r.filename, str) and r.top.dtype != object and r.bottom.dtype != object):
+        raise pickle.UnpicklingError("code row is not CodeRow(top ndarray, bottom ndarray, filename str)")
     return r.top, r.bottom, r.filename
 
 

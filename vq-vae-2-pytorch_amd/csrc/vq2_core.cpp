@@ -101,5 +101,5 @@ extern "C" int vq2_prof_report(char *buf, size_t cap) {
     return VQ2_OK;
 }
 
-extern "C" int vq2_version(void) { return 1; }
+extern "C" int vq2_version(void) { return VQ2_API_VERSION; }
 extern "C" const char *vq2_last_error(void) { return vq2::g_err; }

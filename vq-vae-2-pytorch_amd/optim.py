@@ -113,11 +113,11 @@ class FusedAdam(torch.optim.Optimizer):
 
 
 # ------------------------------------------------------------------ CycleScheduler
-# fraction of the way STILL TO GO after a proportion u of a segment (1 -> 0): anchoring the value at the segment's
-# end keeps full relative precision where the cosine anneal approaches lr_max/divider/1e4
-_REMAINING = {
-    "linear": lambda u: 1.0 - u,                    # scheduler.py:221-222 (anneal_linear)
-    "cos": lambda u: 0.5 + 0.5 * cos(pi * u),       # scheduler.py:225-228 (anneal_cos)
+# value after a proportion u of a segment that runs start -> end; the arithmetic is written exactly as the reference
+# evaluates it, so the LR trajectory (a double handed to Adam) is BIT-identical to the reference scheduler's
+_ANNEAL = {
+    "linear": lambda start, end, u: start + u * (end - start),                      # scheduler.py:221-222
+    "cos": lambda start, end, u: end + (start - end) / 2 * (cos(pi * u) + 1),       # scheduler.py:225-228
 }
 
 
@@ -137,7 +137,7 @@ class CycleScheduler:
         self.momentum = momentum
         warm = int(n_iter * warmup_proportion)
         self.lengths = (warm, n_iter - warm)
-        self.remaining = (_REMAINING[phase[0]], _REMAINING[phase[1]])
+        self.anneal = (_ANNEAL[phase[0]], _ANNEAL[phase[1]])
         lo = lr_max / divider
         self.lr_ends = ((lo, lr_max), (lr_max, lo / 1e4))
         self.mom_ends = None if momentum is None else ((momentum[0], momentum[1]), (momentum[1], momentum[0]))
@@ -150,13 +150,11 @@ class CycleScheduler:
         if self.lengths[seg] == 0:
             # the reference divides by the segment length on its first step (scheduler.py:241): same failure
             raise ZeroDivisionError("CycleScheduler: a schedule segment has no iterations (n_iter too small)")
-        w = self.remaining[seg](done / self.lengths[seg])
-        a, b = self.lr_ends[seg]
-        lr = b + (a - b) * w
+        u = done / self.lengths[seg]
+        lr = self.anneal[seg](*self.lr_ends[seg], u)
         mom = None
         if self.mom_ends is not None:
-            a, b = self.mom_ends[seg]
-            mom = b + (a - b) * w
+            mom = self.anneal[seg](*self.mom_ends[seg], u)
         return lr, mom
 
     def step(self):

@@ -94,8 +94,12 @@ class Stage1Trainer:
             inside = {id(p) for p in self.arena.params}
             for t in list(self.model.parameters()) + list(self.model.buffers()):
                 if id(t) not in inside:
-                    self.comm.broadcast(t.data, 0)
+                    self.comm.broadcast(t.detach(), 0)     # (detach() shares the version counter; .data does not)
         ops.touch_weights(self.arena.params)
+        # the codebooks were just overwritten (NativeComm writes through raw pointers, which no version counter sees):
+        # anything a Quantize derived from its OLD codebook is stale now
+        for q in self.quantizers:
+            q.invalidate_prepared()
 
     def _late_grad_ready(self, _param):
         self._late_seen += 1

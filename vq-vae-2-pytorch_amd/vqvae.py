@@ -128,6 +128,13 @@ class Quantize(nn.Module):
             return self._prep
         return None
 
+    def invalidate_prepared(self):
+        """Call after writing `embed` behind autograd's back (`embed.data.copy_()`, a raw-pointer collective, a foreign
+        kernel): tensor._version does not move for those, so the cached (embedT, ||e||^2) would go stale silently."""
+        self._prep = None
+        self._prep_key = None
+        self._raw_updates += 1
+
     def _ema_update(self, stats):
         # FRESH buffers every time: the previous pair may still be referenced by the autograd graph of the forward that
         # searched the pre-update codebook (the drop-in path updates inside forward, before backward reads embedT)
