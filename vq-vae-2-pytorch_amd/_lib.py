@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvq2.so")
+# VQ2_LIB: an alternative build of the SAME sources (kernel A/B experiments, scripts/build_variant.sh)
+LIB_PATH = os.environ.get("VQ2_LIB") or os.path.join(_HERE, "libvq2.so")
 
 c_f32p = C.c_void_p
 c_stream = C.c_void_p

@@ -22,7 +22,12 @@ namespace vq2 {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef VQ2_RB_WRITE_AFTER
+#define VQ2_RB_WRITE_AFTER 1   // staging order of the slice pipelines (A/B builds: scripts/build_variant.sh)
+#endif
+
 namespace rb {
+constexpr bool WRITE_AFTER = VQ2_RB_WRITE_AFTER != 0;
 constexpr unsigned RSRC_FLAGS = 0x00020000;
 constexpr int OOB = 0x7F000000;   // >= num_records of every descriptor (tensors are checked to be smaller), and
                                   // OOB + any in-tensor slice offset does not wrap
@@ -35,10 +40,14 @@ constexpr int CM = 32;                    // mid channels (n_res_channel)
 constexpr int CC = 128;                   // block channels
 constexpr int A_F4 = NPATCH * CS / 4;     // 720 float4 per activation slice
 constexpr int B_F4 = 9 * CM * CS / 4;     // 1152 float4 per weight slice
-constexpr int A_FLOATS = NPATCH * LDK;    // 3600
-constexpr int B_FLOATS = 9 * CM * LDK;    // 5760
+// LDS buffers are padded to whole staging passes (256 threads x float4): every thread then stores every float4 it
+// loaded, the out-of-patch ones (offset OOB: the range check returned zeros) into rows nobody reads.  With the stores
+// predicated instead, hipcc sinks the LOAD into the predicated block and waits vmcnt(0) right behind it.
+constexpr int A_FLOATS = ((A_F4 + 255) / 256) * 64 * LDK;    // 192 rows: 3840
+constexpr int B_FLOATS = ((B_F4 + 255) / 256) * 64 * LDK;    // 320 rows: 6400
 constexpr int LDR = CM + 4;               // pitch of the r tile and the W2 panel in LDS
-constexpr size_t LDS_BYTES = (size_t)2 * (A_FLOATS + B_FLOATS) * sizeof(float);   // 74,880: two workgroups per CU
+constexpr size_t LDS_BYTES = (size_t)2 * (A_FLOATS + B_FLOATS) * sizeof(float);   // 81,920: exactly two workgroups per CU
+static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 static_assert(128 * LDR <= 2 * (A_FLOATS + B_FLOATS), "stage-2 aliases fit in the stage-1 buffers");
 }  // namespace rb
 
@@ -53,10 +62,27 @@ struct ResFwdParams {
     int N, H, W, ldx, ldr, ldy;
     int tiles_x, tiles_y;
     int relu_out;
+    int dephase, first_round;   // see dephase_start
+    unsigned long long *stamps; // diagnostic (vq2_debug_set_rb_stamps): s_memtime at the phase boundaries of 2 workgroups
 };
 
 __device__ __forceinline__ float4 u4_as_f4(u32x4 v) {
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// De-phased start.  Two workgroups share a CU (one wave of each per SIMD).  Launched together they run in lock-step:
+// both fetch their first slices together, share the matrix pipe through their MFMA phases and burst their epilogue
+// stores together, so memory phases never sit beside matrix phases.  The workgroup that arrives in the SECOND wave slot
+// of its SIMD (HW_REG_HW_ID[3:0] != 0) during the launch's first resident round waits `cycles` before it starts; from
+// then on the two stay out of phase (a freed slot is refilled when ITS workgroup ends).  While the second one waits,
+// the first has the matrix pipe to itself, so the wait is not lost time.  Speed only: results cannot depend on it.
+__device__ __forceinline__ void dephase_start(int cycles, int first_round_blocks) {
+    if (cycles <= 0 || (int)blockIdx.x >= first_round_blocks) return;
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    if ((hw & 15u) == 0u) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)cycles) __builtin_amdgcn_s_sleep(8);
 }
 
 __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const ResFwdParams P) {
@@ -74,6 +100,15 @@ __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const ResFwdParams
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wq = wave;
     const int l31 = lane & 31, fk = 4 * (lane >> 5);
+    const int stamp_slot = (P.stamps && (blockIdx.x == 8 || blockIdx.x == 520)) ? (blockIdx.x == 8 ? 0 : 1) : -1;
+    auto stamp = [&](int i) {
+        if (stamp_slot >= 0 && lane == 0) {
+            P.stamps[(stamp_slot * 4 + wq) * 8 + i] = __builtin_amdgcn_s_memtime();
+            if (i == 0 || i == 5) P.stamps[(stamp_slot * 4 + wq) * 8 + (i == 0 ? 6 : 7)] = __builtin_amdgcn_s_memrealtime();
+        }
+    };
+    stamp(0);
+    dephase_start(P.dephase, P.first_round);
     const int tiles = P.tiles_x * P.tiles_y;
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
     const int n = vid / tiles;
@@ -110,25 +145,23 @@ __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const ResFwdParams
         }
     }
     const int st_off = (tid >> 2) * LDK + (tid & 3) * 4;   // + (NT/4)*LDK per j
-    u32x4 ra[A_LD], rb_[B_LD];
-    auto issue_loads = [&](int s) {
+    struct Slice { u32x4 a[A_LD], b[B_LD]; };
+    auto issue_loads = [&](int s, Slice &r) {
         const int soff = s * CS * 4;
 #pragma unroll
-        for (int j = 0; j < A_LD; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, a_off[j], soff, 0);
+        for (int j = 0; j < A_LD; ++j) r.a[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, a_off[j], soff, 0);
 #pragma unroll
-        for (int j = 0; j < B_LD; ++j) rb_[j] = __builtin_amdgcn_raw_buffer_load_b128(rw1, b_off[j], soff, 0);
+        for (int j = 0; j < B_LD; ++j) r.b[j] = __builtin_amdgcn_raw_buffer_load_b128(rw1, b_off[j], soff, 0);
     };
-    auto store_slice = [&](int buf) {
+    auto store_slice = [&](int buf, const Slice &r) {
         float *a = As + buf * A_FLOATS + st_off;
         float *b = Bs + buf * B_FLOATS + st_off;
 #pragma unroll
         for (int j = 0; j < A_LD; ++j)
-            if ((j + 1) * NT <= A_F4 || tid + NT * j < A_F4)
-                *reinterpret_cast<float4 *>(a + j * (NT / 4) * LDK) = relu4(u4_as_f4(ra[j]));   // first ReLU of the block
+            *reinterpret_cast<float4 *>(a + j * (NT / 4) * LDK) = relu4(u4_as_f4(r.a[j]));   // first ReLU of the block
 #pragma unroll
         for (int j = 0; j < B_LD; ++j)
-            if ((j + 1) * NT <= B_F4 || tid + NT * j < B_F4)
-                *reinterpret_cast<float4 *>(b + j * (NT / 4) * LDK) = u4_as_f4(rb_[j]);
+            *reinterpret_cast<float4 *>(b + j * (NT / 4) * LDK) = u4_as_f4(r.b[j]);
     };
 
     f32x16 acc1;
@@ -184,32 +217,64 @@ __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const ResFwdParams
     f32x16 acc2[NJ];     // starts as the skip path x (vqvae.py:94); the 1x1 GEMM accumulates on top
     float4 w2f[NJ][CM / 8];   // this lane's B fragments of the 1x1 weight, straight from L2 (16 KB panel, no LDS trip)
 
-    issue_loads(0);
-    store_slice(0);
+    // Pipeline (one barrier per slice): the registers hold slice s+1 when iteration s begins (requested a whole MFMA
+    // phase earlier); it goes to the LDS buffer that every wave finished reading before the last barrier, slice s+2 is
+    // requested at once, then the 72 MFMAs of slice s -- the barrier follows them directly (no load wait and no LDS
+    // stores between the last MFMA of one slice and the first of the next).  Slices 0 and 1 are requested back to back
+    // into two register sets, so the peeled first iteration does not wait for a request it has just made.
+    Slice R0, R1;
+    issue_loads(0, R0);
+    issue_loads(1, R1);
+    store_slice(0, R0);
     __syncthreads();
-    for (int s = 0; s < NS; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < NS) {
-            issue_loads(s + 1);
-        } else {   // last slice: fetch what stage 2 needs behind the 72 MFMAs
+    stamp(1);
+    auto stage2_prefetch = [&]() {   // what stage 2 needs, fetched behind the last slice's 72 MFMAs
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int k8 = 0; k8 < CM / 8; ++k8)
-                    w2f[j][k8] = u4_as_f4(__builtin_amdgcn_raw_buffer_load_b128(
-                        rw2, ((j * 32 + l31) * CM + fk + 8 * k8) * 4, 0, 0));
+            for (int k8 = 0; k8 < CM / 8; ++k8)
+                w2f[j][k8] = u4_as_f4(__builtin_amdgcn_raw_buffer_load_b128(
+                    rw2, ((j * 32 + l31) * CM + fk + 8 * k8) * 4, 0, 0));
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    acc2[j][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xoff[r] + j * 128, 0, 0));
-        }
+            for (int r = 0; r < 16; ++r)
+                acc2[j][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xoff[r] + j * 128, 0, 0));
+    };
+    if (WRITE_AFTER) {
+        store_slice(1, R1);
+        issue_loads(2, R0);
         __builtin_amdgcn_sched_barrier(0);   // the fetches must be in flight BEFORE the 72 MFMAs, not sunk behind them
-        compute(buf);
+        compute(0);
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < NS) store_slice(buf ^ 1);
         __syncthreads();
+        for (int s = 1; s < NS; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < NS) store_slice(buf ^ 1, R0);
+            if (s + 2 < NS) issue_loads(s + 2, R0);
+            else if (s + 1 == NS) stage2_prefetch();
+            __builtin_amdgcn_sched_barrier(0);
+            compute(buf);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+        }
+    } else {   // write-before-barrier order: slice s+1 is requested in front of the MFMAs of slice s and stored behind them
+        __builtin_amdgcn_sched_barrier(0);
+        compute(0);
+        __builtin_amdgcn_sched_barrier(0);
+        store_slice(1, R1);
+        __syncthreads();
+        for (int s = 1; s < NS; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < NS) issue_loads(s + 1, R0); else stage2_prefetch();
+            __builtin_amdgcn_sched_barrier(0);
+            compute(buf);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < NS) store_slice(buf ^ 1, R0);
+            __syncthreads();
+        }
     }
+    stamp(2);
     // every wave is past its last fragment read: the staging buffers may be overwritten
     {   // r = relu(acc1 + b1): to LDS for stage 2 and to HBM for the backward pass
         const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(P.r, 0, npix * P.ldr * 4, RSRC_FLAGS);
@@ -226,6 +291,7 @@ __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const ResFwdParams
     }
     // a wave reads back only the 32 rows it wrote itself (LDS operations of one wave complete in order): no barrier
 
+    stamp(3);
     // ---- stage 2: 1x1 conv on the r tile, on top of x + b2
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -248,6 +314,7 @@ __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const ResFwdParams
             }
         }
     }
+    stamp(4);
     // ---- epilogue: optional trailing ReLU (vqvae.py:122,144), store
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(P.y, 0, npix * P.ldy * 4, RSRC_FLAGS);
     const bool relu_out = P.relu_out != 0;
@@ -259,6 +326,8 @@ __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const ResFwdParams
             v = relu_floor(v, relu_out ? 0 : (int)0x80000000);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, yoff[r] + j * 128, 0, 0);
         }
+    if (stamp_slot >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(5);
 }
 
 
@@ -295,9 +364,11 @@ struct ResBwdParams {
     float *b2_slab;    // [grid][128 co]        partial 1x1 bias gradients (with w2_slab)
     int N, H, W, ldg, ldr, ldx, lddh, lddx;
     int tiles_x, tiles_y;
+    int dephase, first_round;     // see dephase_start
     unsigned long long *stamps;   // diagnostic (vq2_debug_set_stamps): s_memtime at the phase boundaries of 2 workgroups
 };
 
+template <bool SAME_LD>
 __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdParams P) {
     using namespace rbb;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -310,9 +381,14 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdP
     const int l31 = lane & 31, fk = 4 * (lane >> 5), rowq = 4 * (lane >> 5);
     const int stamp_slot = (P.stamps && (blockIdx.x == 8 || blockIdx.x == 520)) ? (blockIdx.x == 8 ? 0 : 1) : -1;
     auto stamp = [&](int i) {
-        if (stamp_slot >= 0 && lane == 0) P.stamps[(stamp_slot * 4 + wq) * 8 + i] = __builtin_amdgcn_s_memtime();
+        if (stamp_slot >= 0 && lane == 0) {
+            P.stamps[(stamp_slot * 4 + wq) * 8 + i] = __builtin_amdgcn_s_memtime();
+            // slots 6 / 7: the 100 MHz real-time counter at the first / last stamp (in-kernel clock = cycles / time)
+            if (i == 0 || i == 5) P.stamps[(stamp_slot * 4 + wq) * 8 + (i == 0 ? 6 : 7)] = __builtin_amdgcn_s_memrealtime();
+        }
     };
     stamp(0);
+    dephase_start(P.dephase, P.first_round);
     const int tiles = P.tiles_x * P.tiles_y;
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
     const int n = vid / tiles;
@@ -345,25 +421,27 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdP
     const int wa_off = ((tid >> 3) * CC) * 4 + (tid & 7) * 16;          // row cm = tid>>3 of the [32][128] panel
     const int st8 = (tid >> 3) * LDA + (tid & 7) * 4;                   // LDS float offset of float4 number tid (+32 rows per j)
     constexpr int NSA = CC / SA;
-    u32x4 rga[GA_LD], rwa;
-    auto issue_a = [&](int s) {
+    struct SliceA { u32x4 g[GA_LD], w; };
+    auto issue_a = [&](int s, SliceA &r) {
         const int soff = s * SA * 4;
 #pragma unroll
-        for (int j = 0; j < GA_LD; ++j) rga[j] = __builtin_amdgcn_raw_buffer_load_b128(rg, ga_off[j], soff, 0);
-        rwa = __builtin_amdgcn_raw_buffer_load_b128(rw2, wa_off, soff, 0);
+        for (int j = 0; j < GA_LD; ++j) r.g[j] = __builtin_amdgcn_raw_buffer_load_b128(rg, ga_off[j], soff, 0);
+        r.w = __builtin_amdgcn_raw_buffer_load_b128(rw2, wa_off, soff, 0);
     };
-    auto store_a = [&](int s) {
+    auto store_a = [&](int s, const SliceA &r) {
         const int buf = s & 1;
         float *a = Ga + buf * GA_FLOATS + st8;
+        // GA_LD * 256 float4 = 192 rows exactly: every thread stores everything it loaded (rows >= 180: zeros)
 #pragma unroll
-        for (int j = 0; j < GA_LD; ++j)
-            if ((j + 1) * 256 <= NPATCH * (SA / 4) || tid + 256 * j < NPATCH * (SA / 4))
-                *reinterpret_cast<float4 *>(a + j * 32 * LDA) = u4_as_f4(rga[j]);
-        *reinterpret_cast<float4 *>(Wa + buf * WA_FLOATS + st8) = u4_as_f4(rwa);
+        for (int j = 0; j < GA_LD; ++j) *reinterpret_cast<float4 *>(a + j * 32 * LDA) = u4_as_f4(r.g[j]);
+        *reinterpret_cast<float4 *>(Wa + buf * WA_FLOATS + st8) = u4_as_f4(r.w);
     };
+    static_assert(GA_LD * 256 == PROWS * (SA / 4), "the staging passes cover the padded patch exactly");
     // this wave's patch row blocks: wq, and wq + 4 for waves 0 and 1 (6 blocks of 32 rows cover the 180 patch rows)
     const int nblk = wq < 2 ? 2 : 1;
-    issue_a(0);         // first in the queue: loads return in order, and only this slice gates the first MFMA
+    SliceA RA0, RA1;
+    issue_a(0, RA0);    // first in the queue: loads return in order, and only this slice gates the first MFMA
+    issue_a(1, RA1);
     int pixA[2];        // pixel of patch row 32*b + l31 (this lane's GEMM row), per block
     float rmask[2][16];
 #pragma unroll
@@ -371,9 +449,12 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdP
         pixA[bi] = patch_pix(32 * (wq + 4 * bi) + l31);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
+            // (the load is UNCONDITIONAL with a poisoned offset for the waves that have no second block: written as
+            //  `cond ? load : 0` hipcc branches around every load and waits vmcnt(0) behind each -- 16 dependent memory
+            //  round trips in front of the first MFMA, the whole "prologue" of round 2's stamps)
             const int pix = __shfl(pixA[bi], rowq + (q & 3) + 8 * (q >> 2), 64);
-            rmask[bi][q] = (bi < nblk) ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                                             rr, pix >= 0 ? pix * P.ldr * 4 + l31 * 4 : OOB, 0, 0)) : 0.f;
+            rmask[bi][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                rr, (bi < nblk && pix >= 0) ? pix * P.ldr * 4 + l31 * 4 : OOB, 0, 0));
         }
     }
     f32x16 accA[2];
@@ -395,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdP
         const int q = 2 * kk + (lane >> 5);                // this lane's pixel of MFMA step kk: tile row 2*wq + q/16
         const int gy = y0 + 2 * wq + (q >> 4), gx = x0 + (q & 15);
         const int pix = (gy < P.H && gx < P.W) ? (n * P.H + gy) * P.W + gx : -1;
-        rB[kk] = fuse_w2 ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, pix >= 0 ? pix * P.ldr * 4 + l31 * 4 : OOB, 0, 0)) : 0.f;
+        rB[kk] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, (fuse_w2 && pix >= 0) ? pix * P.ldr * 4 + l31 * 4 : OOB, 0, 0));
     }
     // first tap panel of phase B: fetched behind the last phase-A slice
     const int wb_goff = ((tid >> 3) * 9 * CM) * 4 + (tid & 7) * 16;     // row ci = tid>>3 (+32 per j), tap 0
@@ -409,13 +490,20 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdP
         for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(Wb + buf * WB_FLOATS + st8 + j * 32 * LDA) = u4_as_f4(rwb[j]);
     };
 
-    store_a(0);
+    store_a(0, RA0);
     __syncthreads();
     stamp(1);
+    // same pipeline as the forward kernel: slice s+1 goes from registers to LDS at the START of iteration s, the next
+    // request follows at once, the barrier directly follows the MFMAs
 #pragma unroll
     for (int s = 0; s < NSA; ++s) {
         const int buf = s & 1;
-        if (s + 1 < NSA) issue_a(s + 1); else issue_b(0);
+        if (WRITE_AFTER) {
+            if (s + 1 < NSA) store_a(s + 1, s == 0 ? RA1 : RA0);   // (slices 0 and 1 were requested back to back)
+            if (s + 2 < NSA) issue_a(s + 2, RA0); else if (s + 2 == NSA) issue_b(0);
+        } else {
+            if (s > 0 && s + 1 < NSA) issue_a(s + 1, RA0); else if (s + 1 == NSA) issue_b(0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         {
             const float *b = Wa + buf * WA_FLOATS + l31 * LDA + fk;
@@ -455,7 +543,7 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdP
             if (lane < 32) wr[16 * 64 + lane] = bs;
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < NSA) store_a(s + 1);
+        if (!WRITE_AFTER && s + 1 < NSA) store_a(s + 1, s == 0 ? RA1 : RA0);
         __syncthreads();
         if (fuse_w2) {   // wave wq sums accumulator rows 4*wq..4*wq+3 of the four partial blocks; wave 0 the bias partials
             float *slab = P.w2_slab + ((size_t)blockIdx.x * CC + s * 32) * CM;
@@ -472,7 +560,11 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdP
         }
     }
     stamp(2);
-    // every wave is past its last phase-A fragment read: Dh and Wb may overwrite the slice buffers
+    // every wave is past its last phase-A fragment read: Dh and Wb may overwrite the slice buffers.  Tap 0's panel
+    // (requested two slices ago) goes to LDS first and tap 1's is requested before the dh write, so that neither is
+    // waited for at a barrier.
+    store_b(0);
+    if (WRITE_AFTER) issue_b(1);
     {
         const __amdgpu_buffer_rsrc_t rdh = __builtin_amdgcn_make_buffer_rsrc(P.dh, 0, npix * P.lddh * 4, RSRC_FLAGS);
 #pragma unroll
@@ -493,7 +585,6 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdP
             }
         }
     }
-    store_b(0);
     __syncthreads();
     stamp(3);
 
@@ -509,30 +600,43 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdP
     // workgroups reach their epilogue together: 200 MB of mask + skip + store traffic in lock-step otherwise):
     // taps 0-3 fetch the outer-ReLU mask x of column block `tap` (folded to one bit per element a tap later),
     // taps 5-8 fetch the skip gradient g of column block `tap - 5` into registers.
-    int pixr[16];
+    // byte offset of (pixel of accumulator register q, channel l31) in x -- and in g and dx when their pixel strides equal
+    // x's (SAME_LD; every launch of the train step): computed ONCE, the column block goes into the immediate/scalar
+    // offset.  (Recomputed per load it was ~6 vector instructions + an exec-mask pair per load, 16 loads per tap.)
+    int poff[16];
+    int pixr[SAME_LD ? 1 : 16];
     {
         const int gy = y0 + 2 * wq + (l31 >> 4), gx = x0 + txr;
         const int pix_lane = (gy < P.H && gx < P.W) ? (n * P.H + gy) * P.W + gx : -1;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) pixr[q] = __shfl(pix_lane, rowq + (q & 3) + 8 * (q >> 2), 64);
+        for (int q = 0; q < 16; ++q) {
+            const int pix = __shfl(pix_lane, rowq + (q & 3) + 8 * (q >> 2), 64);
+            poff[q] = pix >= 0 ? pix * (P.ldx * 4) + l31 * 4 : OOB;
+            if (!SAME_LD) pixr[q] = pix;
+        }
     }
     float mtmp[16], gres[4][16];
     unsigned mbits[2] = {0u, 0u};
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int buf = tap & 1;
-        if (tap + 1 < 9) issue_b(tap + 1);
+        if (WRITE_AFTER) {
+            if (tap + 1 < 9) store_b(buf ^ 1);
+            if (tap + 2 < 9) issue_b(tap + 2);
+        } else if (tap + 1 < 9) {
+            issue_b(tap + 1);
+        }
         if (tap < 4) {
 #pragma unroll
             for (int q = 0; q < 16; ++q)
-                mtmp[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                    rx, pixr[q] >= 0 ? pixr[q] * P.ldx * 4 + l31 * 4 + tap * 128 : OOB, 0, 0));
+                mtmp[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, poff[q], tap * 128, 0));
         }
         if (tap >= 5) {
 #pragma unroll
             for (int q = 0; q < 16; ++q)
                 gres[tap - 5][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                    rg, pixr[q] >= 0 ? pixr[q] * P.ldg * 4 + l31 * 4 + (tap - 5) * 128 : OOB, 0, 0));
+                    rg, SAME_LD ? poff[q] : (pixr[SAME_LD ? 0 : q] >= 0 ? pixr[SAME_LD ? 0 : q] * P.ldg * 4 + l31 * 4 : OOB),
+                    (tap - 5) * 128, 0));
         }
         __builtin_amdgcn_sched_barrier(0);
         {
@@ -556,7 +660,7 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdP
 #pragma unroll
             for (int q = 0; q < 16; ++q) mbits[tap >> 1] |= (mtmp[q] > 0.f ? 1u : 0u) << ((tap & 1) * 16 + q);
         }
-        if (tap + 1 < 9) store_b(buf ^ 1);
+        if (!WRITE_AFTER && tap + 1 < 9) store_b(buf ^ 1);
         __syncthreads();
     }
     stamp(4);
@@ -568,16 +672,35 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdP
         for (int q = 0; q < 16; ++q) {
             float v = ((mbits[j >> 1] >> ((j & 1) * 16 + q)) & 1u) ? acc[j][q] : 0.f;
             v += gres[j][q];
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rdx, pixr[q] >= 0 ? pixr[q] * P.lddx * 4 + l31 * 4 + j * 128 : OOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(
+                __float_as_uint(v), rdx,
+                SAME_LD ? poff[q] : (pixr[SAME_LD ? 0 : q] >= 0 ? pixr[SAME_LD ? 0 : q] * P.lddx * 4 + l31 * 4 : OOB), j * 128, 0);
         }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (stamp_slot >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp(5);
 }
 
 }  // namespace vq2
 
-static unsigned long long *g_rb_stamps = nullptr;
-extern "C" int vq2_debug_set_rb_stamps(unsigned long long *buf) { g_rb_stamps = buf; return VQ2_OK; }
+// De-phased start (dephase_start above): only when the launch has more workgroups than one per CU (otherwise nobody
+// shares a SIMD) -- cycles from VQ2_RB_DEPHASE_FWD / VQ2_RB_DEPHASE_BWD (0 = off).
+static void rb_dephase(int grid, int bwd, int *cycles, int *first_round) {
+    static const int c_fwd = getenv("VQ2_RB_DEPHASE_FWD") ? atoi(getenv("VQ2_RB_DEPHASE_FWD")) : 0;
+    static const int c_bwd = getenv("VQ2_RB_DEPHASE_BWD") ? atoi(getenv("VQ2_RB_DEPHASE_BWD")) : 0;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    *cycles = grid > cus ? (bwd ? c_bwd : c_fwd) : 0;
+    *first_round = 2 * cus;
+}
+
+static unsigned long long *g_rb_stamps = nullptr, *g_rb_stamps_fwd = nullptr;
+// buf[64]: backward kernel; buf + 64 (another 64 words): forward kernel
+extern "C" int vq2_debug_set_rb_stamps(unsigned long long *buf) { g_rb_stamps = buf; g_rb_stamps_fwd = buf ? buf + 64 : nullptr; return VQ2_OK; }
 
 extern "C" int vq2_resblock_supported(int32_t C, int32_t Cm) { return (C == vq2::rb::CC && Cm == vq2::rb::CM) ? 1 : 0; }
 
@@ -604,6 +727,8 @@ extern "C" int vq2_resblock_fwd(int32_t N, int32_t H, int32_t W, int32_t C, int3
     P.tiles_x = (W + rb::TW - 1) / rb::TW; P.tiles_y = (H + rb::TH - 1) / rb::TH;
     P.relu_out = (flags & VQ2_RELU_OUT) != 0;
     const int grid = N * P.tiles_x * P.tiles_y;
+    rb_dephase(grid, 0, &P.dephase, &P.first_round);
+    P.stamps = g_rb_stamps_fwd;
     hipStream_t s = to_stream(stream);
     const char *name = "resblock_fwd";
     if (prof_enabled()) name = prof_label("resblock_fwd|M=%d,C=%d,Cm=%d", N * H * W, C, Cm);
@@ -666,7 +791,13 @@ extern "C" int vq2_resblock_bwd_data(int32_t N, int32_t H, int32_t W, int32_t C,
     P.w2_slab = static_cast<float *>(w2_ws);
     P.b2_slab = w2_ws ? P.w2_slab + (size_t)grid * C * Cm : nullptr;
     const size_t lds = w2_ws ? rbb::LDS_BYTES_W2 : rbb::LDS_BYTES;
-    allow_big_lds(resblock_bwd_data_kernel, lds);
-    hipLaunchKernelGGL(resblock_bwd_data_kernel, dim3(grid), dim3(256), lds, s, P);
+    rb_dephase(grid, 1, &P.dephase, &P.first_round);
+    if (ldg == ldx && lddx == ldx) {
+        allow_big_lds(resblock_bwd_data_kernel<true>, lds);
+        hipLaunchKernelGGL(resblock_bwd_data_kernel<true>, dim3(grid), dim3(256), lds, s, P);
+    } else {
+        allow_big_lds(resblock_bwd_data_kernel<false>, lds);
+        hipLaunchKernelGGL(resblock_bwd_data_kernel<false>, dim3(grid), dim3(256), lds, s, P);
+    }
     return check_launch("resblock_bwd_data_kernel");
 }
