@@ -215,8 +215,12 @@ def main():
             "roofline": roof,
         }
         if trainer.dp:
+            # proof that the collective path saw `world` ranks: the communicator's own world size, the bytes of every
+            # bucket it moved per step and how many of them left from a backward hook (overlapped with backward)
             line["collectives"] = {"backend": dist.get_backend(), "data_path": trainer.comm.name,
-                                   "early_tail_buckets": trainer.early_buckets,
+                                   "world": trainer.comm.world(), "buckets_per_step": len(trainer.bucket_bytes) or 1,
+                                   "bucket_bytes": trainer.bucket_bytes or {"all": 4 * trainer.arena.flat_g.numel()},
+                                   "early_buckets": trainer.early_buckets,
                                    "steps": args.steps + args.warmup}
         if parity is not None:
             line["parity"] = parity

@@ -26,7 +26,7 @@ def main():
     info = {"data_path": vqvae2_amd.distributed.data_comm().name}
     for case in ("tiny", "default64"):
         sd, losses, tr = run_case(vqvae2_amd, case)
-        assert tr.dp and tr.comm_stream is not None and tr.split_off is not None
+        assert tr.dp and tr.comm_stream is not None and len(tr.buckets) == 3
         assert isinstance(tr.comm, vqvae2_amd.distributed.NativeComm) == want_native
         info[case] = {"early": tr.early_buckets, "losses": losses}
         np.savez(os.path.join(out, f"{case}.npz"), **sd)

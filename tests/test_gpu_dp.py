@@ -46,8 +46,11 @@ def _run(world, rank, imgs, steps, warm=False):
     for _ in range(steps):
         out = tr.step(imgs.cuda())
     torch.cuda.synchronize()
-    if world > 1:   # the decoder-side gradient bucket went out from the backward hook (overlap path), every step
-        assert tr.split_off is not None and tr.early_buckets == steps
+    if world > 1:   # the tail AND the middle bucket went out from backward hooks (overlap path), every step
+        assert [b[0] for b in tr.buckets] == ["tail", "middle", "head"] and tr.early_buckets == 2 * steps
+        lo_hi = sorted((lo, hi) for _, lo, hi, _ in tr.buckets)       # the three slices tile the gradient buffer
+        assert lo_hi[0][0] == 0 and lo_hi[-1][1] == tr.arena.flat_g.numel()
+        assert all(a[1] == b[0] for a, b in zip(lo_hi[:-1], lo_hi[1:]))
     return {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}, float(out["loss"])
 
 
@@ -123,7 +126,7 @@ def _ddp_run(amd, world, rank, steps=2, batch=4):
         loss = crit(dec, img) + 0.25 * latent.mean()
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     torch.cuda.synchronize()
     return {k.replace("module.", "", 1): v.detach().cpu().numpy() for k, v in model.state_dict().items()}, losses
 

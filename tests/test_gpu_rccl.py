@@ -45,7 +45,7 @@ def test_trainer_over_rccl_world1_equals_plain_run(tmp_path, comm):
     for case, (cfg, size, batch, steps, seed) in CASES.items():
         sd, losses, tr = run_case(vqvae2_amd, case)
         assert not tr.dp
-        assert info[case]["early"] == steps, "the overlapped tail bucket must go out from the backward hook every step"
+        assert info[case]["early"] == 2 * steps, "tail and middle buckets must go out from backward hooks every step"
         assert info[case]["losses"] == losses
         got = np.load(tmp_path / f"{case}.npz")
         for k, v in sd.items():
@@ -73,7 +73,9 @@ def test_bench_under_torchrun_with_rccl_group():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0
-    assert line["collectives"]["backend"] == "nccl" and line["collectives"]["early_tail_buckets"] == 4
+    c = line["collectives"]
+    assert c["backend"] == "nccl" and c["world"] == 1 and c["early_buckets"] == 8 and c["buckets_per_step"] == 3
+    assert sorted(c["bucket_bytes"]) == ["head", "middle", "tail"] and all(v > 0 for v in c["bucket_bytes"].values())
 
 
 def test_bench_two_ranks_rehearsal_over_gloo():
@@ -87,4 +89,6 @@ def test_bench_two_ranks_rehearsal_over_gloo():
     assert len(lines) == 1, "exactly one JSON line (rank 0)"
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 8 and line["config"]["parallelism"] == "dp2"
-    assert line["scaling"] == "weak" and line["value"] > 0 and line["collectives"]["early_tail_buckets"] == 4
+    c = line["collectives"]
+    assert line["scaling"] == "weak" and line["value"] > 0 and c["early_buckets"] == 8 and c["world"] == 2
+    assert c["buckets_per_step"] == 3 and c["bucket_bytes"]["head"] < c["bucket_bytes"]["middle"] + c["bucket_bytes"]["tail"]

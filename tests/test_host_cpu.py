@@ -216,6 +216,21 @@ def test_extract_code_preprocessing_uses_torchvision_integer_rules(amd):
     assert box(256, 256, 256) == ((256, 256), (0, 0, 256, 256))
 
 
+def test_unsent_bucket_slices_cover_the_gradient_buffer(amd):
+    """Stage1Trainer's fallback after backward: whatever slices the backward hooks did NOT hand to the communicator go
+    out then, as maximal contiguous ranges -- never a gap, never a slice twice (no silent un-reduced gradient)."""
+    import types
+    fake = types.SimpleNamespace(arena=types.SimpleNamespace(flat_g=torch.zeros(100)), _sent=[])
+    unsent = lambda: amd.Stage1Trainer._unsent_slices(fake)
+    assert unsent() == [(0, 100)]                       # no hook fired: one collective over everything
+    fake._sent = [(60, 90)]                             # tail only
+    assert unsent() == [(0, 60), (90, 100)]
+    fake._sent = [(60, 90), (0, 60)]                    # tail + middle: enc_b's slice is what stays exposed
+    assert unsent() == [(90, 100)]
+    fake._sent = [(0, 60), (60, 100)]
+    assert unsent() == []
+
+
 def test_launch_spawns_ranks_and_joins_the_group(amd, tmp_path):
     """distributed.launch (launch.py:22-49) with the gloo backend: two child ranks, environment-first bring-up."""
     out = str(tmp_path / "ranks")

@@ -102,6 +102,9 @@ class TorchComm:
     def broadcast(self, tensor, src=0):
         dist.broadcast(tensor, src)
 
+    def world(self):
+        return dist.get_world_size()
+
 
 class NativeComm:
     """The same exchange through libvq2's own RCCL communicator (include/vq2.h vq2_comm_*): what a host that is
@@ -123,6 +126,10 @@ class NativeComm:
         from ._lib import lib, check
         ptr, n, stream = self._args(tensor)
         check(lib.vq2_comm_broadcast(ptr, n, src, stream), "comm_broadcast")
+
+    def world(self):
+        from ._lib import lib
+        return int(lib.vq2_comm_world())
 
 
 _native = None

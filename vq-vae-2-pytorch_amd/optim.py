@@ -22,10 +22,15 @@ class ParamArena:
     launches then write straight into the flat gradient buffer (ops.conv_wgrad / bias_grad look at
     `param._vq2_grad`).  `extra` floats are appended to the gradient buffer for the VQ statistics."""
 
-    def __init__(self, params, extra=0):
+    def __init__(self, params, extra=0, last=()):
+        """`last`: parameters to place at the END of both buffers (the ones whose gradients arrive last in the backward
+        pass; Stage1Trainer puts enc_b there so that each data-parallel bucket is ONE contiguous slice)."""
         params = [p for p in params if p.requires_grad]
         if not params:
             raise ValueError("ParamArena: no parameters")
+        self.registration_order = list(params)
+        tail_ids = {id(p) for p in last}
+        params = [p for p in params if id(p) not in tail_ids] + [p for p in params if id(p) in tail_ids]
         dev = params[0].device
         if dev.type != "cuda":
             raise RuntimeError("ParamArena: parameters must live on the MI355X (model.cuda() first)")
@@ -51,6 +56,19 @@ class ParamArena:
                 self.offset[id(p)] = off
                 off += sz
         ops.touch_weights(params)
+
+    def canonical(self, flat):
+        """A per-parameter flat state vector (Adam moments) re-ordered from arena order into REGISTRATION order -- the
+        layout checkpoints carry, whatever order this arena uses internally."""
+        return torch.cat([flat[self.offset[id(p)]:self.offset[id(p)] + p.numel()] for p in self.registration_order])
+
+    def from_canonical(self, src, dst):
+        off = 0
+        for p in self.registration_order:
+            dst[self.offset[id(p)]:self.offset[id(p)] + p.numel()].copy_(src[off:off + p.numel()])
+            off += p.numel()
+        if off != src.numel():
+            raise RuntimeError("ParamArena: state vector belongs to a different model")
 
     def grads_ready(self):
         return all(p.grad is not None and p.grad.data_ptr() == p._vq2_grad.data_ptr() for p in self.params)

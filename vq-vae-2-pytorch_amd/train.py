@@ -33,7 +33,11 @@ class Stage1Trainer:
         live = model.live_parameters() if hasattr(model, "live_parameters") else list(model.parameters())
         self.quantizers = [m for m in model.modules() if type(m).__name__ == "Quantize"]
         extra = sum(q.n_embed * (q.dim + 1) for q in self.quantizers)
-        self.arena = ParamArena(live, extra=extra)
+        # enc_b back-propagates LAST: its parameters go to the end of the arena, so that the gradient buffer reads
+        # [EMA statistics | enc_t quantize_conv_t dec_t | quantize_conv_b upsample_t dec | enc_b] and each of the three
+        # data-parallel buckets (below) is one contiguous slice
+        enc_b = getattr(model, "enc_b", None)
+        self.arena = ParamArena(live, extra=extra, last=list(enc_b.parameters()) if enc_b is not None else ())
         off = 0
         for q in self.quantizers:  # EMA statistics ride in the head of the gradient buffer
             n = q.n_embed * (q.dim + 1)
@@ -67,23 +71,43 @@ class Stage1Trainer:
         if self.dp:
             self._sync_initial_state()
         self.pack_plan.run()
-        # Overlap: when the gradients of the layers that back-propagate first (decoder side; they sit at the
-        # TAIL of the arena) are complete, their slice is all-reduced on the side stream while the
-        # encoder is still back-propagating; the head (encoder gradients + EMA statistics) follows.
-        self.split_off = None
-        self.tail_params = []
-        self._late_seen = 0
-        self._bucket_sent = False
-        self.early_buckets = 0      # steps in which the tail bucket went out from the backward hook
-        split = getattr(model, "quantize_conv_b", None)
+        # Overlap (train_vqvae.py:166-171 is DDP's bucketed all-reduce; vqvae.py:58-59 the EMA sums).  The backward pass
+        # produces gradients in the order dec, upsample_t, quantize_conv_b | dec_t, quantize_conv_t, enc_t | enc_b, so
+        # the gradient buffer goes out in THREE contiguous slices, each all-reduced on the communication stream while
+        # the next group is still back-propagating:
+        #   tail    [quantize_conv_b upsample_t dec]             when quantize_conv_b's gradient lands   (~60 %)
+        #   middle  [EMA statistics | enc_t quantize_conv_t dec_t] when enc_t's first conv's gradient lands
+        #   head    [enc_b]                                       after backward: the only exposed part (~1.4 MB)
+        # A bucket goes out early only if every parameter of its slice already owns its gradient slot (autograd happens
+        # to order the graph this way; nothing else guarantees it) -- whatever was not sent early is sent after backward.
+        self.early_buckets = 0      # buckets that went out from a backward hook (all steps)
+        self.bucket_bytes = {}      # name -> bytes of the slice (bench line)
+        self._sent = []             # [lo, hi) slices of flat_g already handed to the communicator in this step
+        self._hooks_seen = {}
+        self.buckets = []           # (name, lo, hi, params of the slice)
+        self._send_early = False
         self.early_flush = os.environ.get("VQ2_EARLY_FLUSH", "1") != "0" and self.ctx.stream is not None
-        if split is not None and (self.early_flush or (self.dp and os.environ.get("VQ2_DP_OVERLAP", "1") != "0")):
-            first = self.arena.offset[id(split.weight)]
-            if self.dp and os.environ.get("VQ2_DP_OVERLAP", "1") != "0":
-                self.split_off = self.arena.n_extra + first
-            self.tail_params = [p for p in self.arena.params if self.arena.offset[id(p)] >= first]
-            split.weight.register_post_accumulate_grad_hook(self._late_grad_ready)
-            split.bias.register_post_accumulate_grad_hook(self._late_grad_ready)
+        overlap = self.dp and os.environ.get("VQ2_DP_OVERLAP", "1") != "0"
+        split = getattr(model, "quantize_conv_b", None)
+        enc_t = getattr(model, "enc_t", None)
+        if split is not None and enc_b is not None and enc_t is not None and (self.early_flush or overlap):
+            a = self.arena
+            off = lambda p: a.n_extra + a.offset[id(p)]
+            lo_tail = off(split.weight)
+            lo_head = min(off(p) for p in enc_b.parameters())
+            total = a.flat_g.numel()
+            inside = lambda lo, hi: [p for p in a.params if lo <= off(p) < hi]
+            self.buckets = [("tail", lo_tail, lo_head, inside(lo_tail, lo_head)),
+                            ("middle", 0, lo_tail, inside(0, lo_tail)),
+                            ("head", lo_head, total, inside(lo_head, total))]
+            self.bucket_bytes = {name: 4 * (hi - lo) for name, lo, hi, _ in self.buckets}
+            self._send_early = overlap
+            for prm in (split.weight, split.bias):
+                prm.register_post_accumulate_grad_hook(lambda _p: self._group_done("tail", 2))
+            if overlap:     # (single GPU: one early slab reduction is enough, a second one only adds a launch)
+                first = enc_t.blocks[0]
+                for prm in (first.weight, first.bias):
+                    prm.register_post_accumulate_grad_hook(lambda _p: self._group_done("middle", 2))
 
     # ------------------------------------------------------------------ data parallel plumbing
     def _sync_initial_state(self):
@@ -101,18 +125,16 @@ class Stage1Trainer:
         for q in self.quantizers:
             q.invalidate_prepared()
 
-    def _late_grad_ready(self, _param):
-        self._late_seen += 1
-        if self._late_seen != 2 or self._bucket_sent:
+    def _group_done(self, name, need):
+        """Post-accumulate hook of the LAST layer of a backward group: reduce the split-K slabs produced so far into the
+        arena (side stream) and, data parallel, hand the group's slice to the communicator while the next group
+        back-propagates."""
+        seen = self._hooks_seen[name] = self._hooks_seen.get(name, 0) + 1
+        if seen != need:
             return
-        # The early bucket is legal only if every parameter of the tail slice has ALREADY produced its gradient
-        # (autograd happens to run upsample_t / dec before quantize_conv_b; nothing else guarantees it): otherwise
-        # keep everything for the single all-reduce after backward.
-        if not all(p.grad is not None and p.grad.data_ptr() == p._vq2_grad.data_ptr() for p in self.tail_params):
-            return
-        # The decoder-side split-K slabs (most of the 546 MB) are reduced into the arena NOW, on the side stream when
-        # there is one, beside the encoder's matrix-bound backward launches -- instead of in one HBM-bound pass after
-        # backward; data parallel: that slice of the gradient buffer then goes out while the encoder back-propagates.
+        _, lo, hi, params = next(b for b in self.buckets if b[0] == name)
+        if not all(p.grad is not None and p.grad.data_ptr() == p._vq2_grad.data_ptr() for p in params):
+            return      # autograd ordered the graph differently: keep the slice for the collective after backward
         side = self.ctx.stream
         if side is not None:
             side.wait_event(torch.cuda.current_stream().record_event())
@@ -122,14 +144,24 @@ class Stage1Trainer:
         else:
             self.ctx.batch.flush()
             ev = torch.cuda.current_stream().record_event()
-        if self.split_off is None:       # single GPU: nothing to send
-            self._bucket_sent = True
+        if not self._send_early:
             return
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(ev)
-            self.comm.all_reduce(self.arena.flat_g[self.split_off:])
-        self._bucket_sent = True
+            self.comm.all_reduce(self.arena.flat_g[lo:hi])
+        self._sent.append((lo, hi))
         self.early_buckets += 1
+
+    def _unsent_slices(self):
+        """Complement of the slices already sent, as maximal contiguous [lo, hi) ranges of flat_g."""
+        out, pos = [], 0
+        for lo, hi in sorted(self._sent):
+            if lo > pos:
+                out.append((pos, lo))
+            pos = max(pos, hi)
+        if pos < self.arena.flat_g.numel():
+            out.append((pos, self.arena.flat_g.numel()))
+        return out
 
     # ------------------------------------------------------------------ the step
     def step(self, img, return_dec=False):
@@ -148,7 +180,7 @@ class Stage1Trainer:
             dec, diff = model(img)
             loss, recon, latent = stage1_loss(dec, diff, img)
             roots, seeds = (loss,), (None,)
-        self._late_seen, self._bucket_sent = 0, False
+        self._sent, self._hooks_seen = [], {}
         self.ctx.active = True
         try:
             torch.autograd.backward(roots, seeds)
@@ -165,10 +197,8 @@ class Stage1Trainer:
             ev = torch.cuda.current_stream().record_event()
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                if self._bucket_sent:
-                    self.comm.all_reduce(self.arena.flat_g[:self.split_off])
-                else:
-                    self.comm.all_reduce(self.arena.flat_g)
+                for lo, hi in self._unsent_slices():     # normally just enc_b's slice; everything if no hook fired
+                    self.comm.all_reduce(self.arena.flat_g[lo:hi])
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         for q in self.quantizers:
             q.apply_deferred_update()
@@ -189,7 +219,9 @@ class Stage1Trainer:
         step count, learning rate / betas, the schedule position."""
         group = self.optimizer.param_groups[0]
         return {"model": {k: v.detach().clone() for k, v in self.model.state_dict().items()},
-                "adam_m": self.optimizer._m.clone(), "adam_v": self.optimizer._v.clone(), "adam_t": self.optimizer._t,
+                # Adam moments in REGISTRATION order (the arena's internal order is an implementation detail)
+                "adam_m": self.arena.canonical(self.optimizer._m), "adam_v": self.arena.canonical(self.optimizer._v),
+                "adam_t": self.optimizer._t,
                 "lr": group["lr"], "betas": tuple(group["betas"]),
                 "scheduler": None if self.scheduler is None else self.scheduler.state_dict()}
 
@@ -202,10 +234,16 @@ class Stage1Trainer:
         self.model.load_state_dict(model_sd)          # copies INTO the arena views: parameters stay re-homed
         ops.touch_weights(self.arena.params)
         if full:
-            if sd["adam_m"].numel() != self.optimizer._m.numel():
+            n_real = sum(p.numel() for p in self.arena.params)
+            if sd["adam_m"].numel() == self.optimizer._m.numel() and sd["adam_m"].numel() != n_real:
+                # a round-2 checkpoint: moments in that arena's padded registration order
+                raise RuntimeError("Stage1Trainer.load_state_dict: optimizer state uses the pre-round-3 padded layout; "
+                                   "re-save it with that version or resume from the model weights alone")
+            if sd["adam_m"].numel() != n_real:
                 raise RuntimeError("Stage1Trainer.load_state_dict: optimizer state belongs to a different model")
-            self.optimizer._m.copy_(sd["adam_m"])
-            self.optimizer._v.copy_(sd["adam_v"])
+            dev = self.optimizer._m.device
+            self.arena.from_canonical(sd["adam_m"].to(dev), self.optimizer._m)
+            self.arena.from_canonical(sd["adam_v"].to(dev), self.optimizer._v)
             self.optimizer._t = int(sd["adam_t"])
             for group in self.optimizer.param_groups:
                 group["lr"], group["betas"] = sd["lr"], tuple(sd["betas"])
