@@ -33,6 +33,9 @@ WORKLOADS = {
     "c4": (256, 32, 8192, "configs[3]: 256x256, n_embed=8192 large codebook, batch 32/GPU"),
     "c5": (512, 8, 512, "configs[4]: 512x512 synthetic, default two-level VQ-VAE-2, batch 8/GPU"),
     "tiny": (64, 4, 512, "debug: 64x64, batch 4"),
+    # SURVEY 8f-4 (not a BASELINE config): the default VQVAE_Deep of vqvae_deep.py:234-261 -- channel 256, ResBlock(256,128)
+    # x6 per stack, embed_dim 256, AdaIN decoder with style_dim 2048 -- through the drop-in module + one-launch Adam
+    "deep": (256, 32, 512, "next-row f4: 256x256, default VQVAE_Deep (26.6 M parameters, style_dim 2048), batch 32/GPU"),
 }
 
 
@@ -94,6 +97,28 @@ def cpu_baseline(size, n_embed, budget_s=7.0):
             "runs": runs}
 
 
+class DeepStep:
+    """The reference's loop body (train_vqvae.py:83-91) on the drop-in VQVAE_Deep: forward(input, style), MSE + 0.25 *
+    latent, backward, Adam -- the optimizer as ONE vq2_adam_step launch over a flat arena (weight gradients land in
+    their arena slots straight from the wgrad kernels)."""
+    dp = False
+
+    def __init__(self, amd, model, style):
+        from vqvae2_amd.optim import FusedAdam, ParamArena
+        live = model.live_parameters()
+        self.amd, self.model, self.style = amd, model, style
+        self.arena = ParamArena(live)
+        self.opt = FusedAdam(live, lr=3e-4, arena=self.arena)
+
+    def step(self, img):
+        self.arena.zero_grad()
+        dec, diff, _ = self.model(img, style=self.style)
+        loss, recon, latent = self.amd.stage1_loss(dec, diff, img)
+        loss.backward()
+        self.opt.step()
+        return {"loss": loss.detach(), "recon": recon, "latent": latent}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -120,10 +145,21 @@ def main():
     if args.batch:
         batch = args.batch
     cfg = O.VQVAEConfig(n_embed=n_embed)
-    model = vqvae2_amd.VQVAE(n_embed=n_embed)
-    model.load_state_dict(O.make_state(cfg, 1234))  # identical replicas on every rank
-    model.to(dev)
-    trainer = vqvae2_amd.Stage1Trainer(model, lr=3e-4)
+    deep = args.workload == "deep"
+    if deep:
+        if world != 1:
+            raise SystemExit("--workload deep is a single-GPU measurement of the drop-in VQVAE_Deep module")
+        from oracle import vqvae_deep_oracle as OD
+        args.no_cpu_baseline = True
+        model = vqvae2_amd.VQVAE_Deep()
+        model.load_state_dict(OD.make_deep_state(OD.DEEP_DEFAULT, 1234, 0.3, 1.5))
+        model.to(dev).train()
+        trainer = DeepStep(vqvae2_amd, model, OD.make_style(batch, OD.DEEP_DEFAULT, 1234).to(dev))
+    else:
+        model = vqvae2_amd.VQVAE(n_embed=n_embed)
+        model.load_state_dict(O.make_state(cfg, 1234))  # identical replicas on every rank
+        model.to(dev)
+        trainer = vqvae2_amd.Stage1Trainer(model, lr=3e-4)
     img = O.make_images(batch, size, 1234, rank=rank).to(dev)  # resident in HBM before timing
 
     def barrier():
@@ -134,7 +170,7 @@ def main():
     # "recon-MSE parity" half of the BASELINE metric, recorded with the number: the first two images through the HIP
     # path and through the CPU oracle (eval forward: same weights, same codebooks), outside the timed region
     parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not deep:
         import torch.nn.functional as F
         st0 = O.make_state(cfg, 1234)
         model.eval()
@@ -206,7 +242,8 @@ def main():
                     "launches_per_step": r["launches"] // max(sampled, 1), "sampled_steps": sampled,
                     "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2)}
         line = {
-            "metric": "images/sec VQ-VAE-2 256px train step", "value": round(value, 2), "unit": "images/s",
+            "metric": "images/sec VQVAE_Deep 256px train step (not the BASELINE metric)" if deep else
+                      "images/sec VQ-VAE-2 256px train step", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "global_batch": batch * world, "image": size, "n_embed": n_embed,
@@ -228,6 +265,10 @@ def main():
             line["cpu_baseline"] = cpu_baseline(size, n_embed)
         if kernels:
             line["kernel_ms_per_step"] = {k: round(v["ms"] / max(sampled, 1), 4) for k, v in fam.items()}
+            if level == 1:   # every GEMM-shaped launch was bracketed: algorithmic FLOPs of the whole step
+                gf = sum(v["flops"] for v in kernels.values()) / max(sampled, 1) / 1e9
+                line["algorithmic_gflop_per_step"] = round(gf, 1)
+                line["step_tflops"] = round(gf / ms, 2)
         if args.kernel_table:
             for v in kernels.values():
                 v["tflops"] = round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)

@@ -44,7 +44,9 @@ class Linear(nn.Module):
     def forward(self, input):
         lead = input.shape[:-1]
         x = input.reshape(-1, 1, 1, self.in_features)
-        y = ops.conv_op(x, self.weight.view(self.out_features, self.in_features, 1, 1), self.bias, self.spec)
+        # the Parameter itself (not a 4-D view of it): the kernels take raw pointers, and the weight gradient can then
+        # land directly in the parameter's slot of a ParamArena (a view has no slot and autograd would copy)
+        y = ops.conv_op(x, self.weight, self.bias, self.spec)
         return y.reshape(*lead, self.out_features)
 
 
@@ -187,6 +189,15 @@ class VQVAE_Deep(nn.Module):
         self.dec = Decoder(embed_dim + embed_dim, out_channel, channel, style_dim, n_res_block, n_res_channel, stride=6)
         self.embed_dim = 2 * embed_dim
         self._out_channel = out_channel
+
+    def live_named_parameters(self):
+        """Parameters that take part in training: everything but the dead `AdainResBlk.conv` stacks
+        (vqvae_deep.py:120-125 builds them, :127-133 never calls them)."""
+        dead = {id(p) for m in self.modules() if isinstance(m, AdainResBlk) for p in m.conv.parameters()}
+        return [(k, p) for k, p in self.named_parameters() if id(p) not in dead]
+
+    def live_parameters(self):
+        return [p for _, p in self.live_named_parameters()]
 
     def encode(self, input):
         """-> (enc_b [B,C,H/8,W/8], enc_t [B,C,H/16,W/16])  (vqvae_deep.py:282-285)."""
