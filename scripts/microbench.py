@@ -59,7 +59,7 @@ def main():
         fl = 2.0 * macs
         relu = 0 if os.environ.get("MB_NORELU") else ops.VQ2_RELU_IN
         t_f = timeit(lambda: ops.conv_forward(spec, x, wt, b, relu))
-        t_d = timeit(lambda: ops.conv_dgrad(spec, x.shape, dy, wt, mask=x))
+        t_d = timeit(lambda: ops.conv_dgrad(spec, x.shape, dy, wt, mask=None if os.environ.get('MB_NOMASK') else x))
         t_w = timeit(lambda: ops.conv_wgrad(spec, x, dy, True, wt, b))
         if os.environ.get("MB_REPEAT"):
             t_f = timeit(lambda: ops.conv_forward(spec, x, wt, b, relu))   # again, after the clocks have settled

@@ -1125,7 +1125,16 @@ static int run_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
         if (P.Co > 64) {
             // K <= 64 (the 1x1 convs out of 32/64 channels): one or two chunks, HBM/epilogue-bound ->
             // 64-row tiles double the workgroups in flight (measured +12 % on 32 -> 128)
-            if (P.K <= 64) return launch_conv_gemm_fast<2, 2, 1, 2, 16>(P, s);
+            if (P.K <= 64) {
+                // N = 192 (data gradient of quantize_conv_b, vqvae.py:189): a 192-wide tile covers the row in ONE pass --
+                // with 128-wide tiles the second column tile is half empty (a quarter of the MFMAs wasted) and the dy
+                // rows are read twice
+                static const int t192 = tune("VQ2_T192", 1);
+                if (P.Co > 128 && P.Co <= 192 && t192 == 1) return launch_conv_gemm_fast<2, 2, 1, 3, 16>(P, s);
+                if (P.Co > 128 && P.Co <= 192 && t192 == 2) return launch_conv_gemm_fast<2, 2, 2, 3, 16>(P, s);
+                if (P.Co > 128 && P.Co <= 192 && t192 == 3) return launch_conv_gemm_fast<4, 1, 1, 6, 16>(P, s);
+                return launch_conv_gemm_fast<2, 2, 1, 2, 16>(P, s);
+            }
             if (tk == 1 && P.K <= 512) return launch_conv_gemm_fast<2, 2, 1, 2, 16>(P, s);   // 64 x 128 for short K
             if (tk == 2 && P.K <= 512) return launch_conv_gemm_fast<2, 2, 1, 2, 32>(P, s);
             static const int t128 = tune("VQ2_T128", 0);
