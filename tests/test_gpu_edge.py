@@ -2,6 +2,9 @@
 layout conversion, stand-alone modules, optimizer and checkpoint round trip -- each against the
 CPU oracle ops (plain torch fp32 on the same seeded inputs)."""
 import io
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -307,3 +310,14 @@ def test_vq_stats_shapes_patterns_and_determinism(amd):
                 np.testing.assert_allclose(outs[0][K:].reshape(K, D).numpy(), sums.numpy(), rtol=2e-5,
                                            atol=2e-5 * float(xh.abs().max()) * max(1.0, float(counts.max()) ** 0.5),
                                            err_msg=f"{(M, D, K, name, sliced)}")
+
+
+def test_general_kernels_with_every_fast_path_switched_off():
+    """The general kernels that the specialised ones replaced -- conv_gemm_kernel (no buffer-descriptor addressing),
+    wgrad_kernel, the four-phase GEMM form of the sub-pixel layers, the two-launch ResBlock -- still back every shape the
+    fast paths decline (k > 5, tensors beyond 2^29 elements).  Run the ragged-shape and fused-flag cases through them in
+    a child process (the library reads its switches once per process)."""
+    env = dict(os.environ, VQ2_FAST="0", VQ2_WFAST="0", VQ2_SUBPIX="0", VQ2_C4="0", VQ2_RB_FUSED="0", VQ2_WSWAP="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "ragged_conv_shapes or channel_slices"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

@@ -625,8 +625,16 @@ def _fullsize_step_checks(amd, cfg, size, batch, seed, sub=2):
         sd = m.state_dict()
         assert float(counts.sum()) == M
         close(sd[f"quantize_{key}.cluster_size"], cs, rtol=1e-6, atol=0, what=f"{key}.cluster_size")
-        # sums of up to ~1e5 rows: the fixed summation tree and index_add's sequential order differ by reassociation
-        close(sd[f"quantize_{key}.embed_avg"], ea, rtol=5e-5, atol=1e-5, what=f"{key}.embed_avg")
+        # embed_avg: exact to 1e-5 wherever a code collects a modest number of rows; a code that sums >= 1e4 rows may
+        # differ by reassociation (fixed summation tree here, index_add's sequential order in the oracle: error
+        # ~ sqrt(rows) * eps of the sum) -- asserted as exactly that: every element beyond 1e-5 belongs to such a code
+        got_ea = sd[f"quantize_{key}.embed_avg"].cpu()
+        err = (got_ea - ea).abs()
+        loose = err > 1e-5 * ea.abs() + 1e-5
+        if bool(loose.any()):
+            heavy = counts >= 1e4
+            assert bool(heavy[loose.any(0)].all()), f"{key}.embed_avg: an element of a lightly used code is off"
+        close(got_ea, ea, rtol=5e-5, atol=1e-5, what=f"{key}.embed_avg")
         close(sd[f"quantize_{key}.embed"], emb, rtol=1e-4, atol=1e-5, what=f"{key}.embed")
         code = F.embedding(got.reshape(x.shape[:-1]), e0.t())
         latent = latent + float((code - x).double().pow(2).mean())
