@@ -231,8 +231,8 @@ def main():
             traffic, tsrc = None, None
             try:
                 with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                    pm = json.load(f).get(dom)
-                if pm and pm.get("workload") == args.workload and pm.get("batch") == batch:
+                    pm = json.load(f).get(args.workload, {}).get(dom)
+                if pm and pm.get("batch") == batch:
                     traffic, tsrc = pm["bytes_per_launch"], pm["source"]
             except OSError:
                 pass

@@ -309,8 +309,13 @@ __device__ __forceinline__ float4 as_f4(u32x4 v) {
 // per-thread (kh, kw) counter) -- all 1,024 tiles of a 64x64-resolution layer are then resident at once: ONE
 // round, so one exposed prologue and one epilogue burst per launch instead of two.
 // UNI (Ci % BK == 0, K % BK == 0: every layer but the 3-channel ones): see the scalar k tracking below.
-template <int WAVES_M, int WAVES_N, int MT, int NT, int BK, bool PIPE, bool RELU_IN, bool OCC4 = false, bool UNI = OCC4, bool TAPIN = false>
+// CLOCK (diagnostic instantiation only, scripts/stamp_conv.py): four workgroups leave their lifetime in shader cycles
+// (s_memtime) and in 10 ns ticks (s_memrealtime) -- the in-kernel clock the chip holds under this kernel's load.
+template <int WAVES_M, int WAVES_N, int MT, int NT, int BK, bool PIPE, bool RELU_IN, bool OCC4 = false, bool UNI = OCC4, bool TAPIN = false,
+          bool CLOCK = false>
 __global__ __launch_bounds__(256, OCC4 ? 4 : ((MT * NT == 4) ? (BK == 16 ? 3 : 2) : 1)) void conv_gemm_fast_kernel(const ConvGemmParams P) {
+    unsigned long long clk_t0 = 0, clk_r0 = 0;
+    if constexpr (CLOCK) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
     constexpr int LDK = BK + 4;
     constexpr int BM = WAVES_M * MT * 32;
     constexpr int BN = WAVES_N * NT * 32;
@@ -622,7 +627,17 @@ __global__ __launch_bounds__(256, OCC4 ? 4 : ((MT * NT == 4) ? (BK == 16 ? 3 : 2
             }
         }
     }
+    if constexpr (CLOCK) {
+        if (P.stamps && tid == 0 && (blockIdx.x & 255) == 8 && blockIdx.x < 1024) {
+            const int slot = blockIdx.x >> 8;
+            P.stamps[slot * 4 + 0] = __builtin_amdgcn_s_memtime() - clk_t0;
+            P.stamps[slot * 4 + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+            P.stamps[slot * 4 + 2] = (unsigned long long)nchunks * (BK / 2) * MT * NT;   // MFMAs of one wave
+        }
+    }
 }
+
+static unsigned long long *g_stamps = nullptr;  // set by vq2_debug_set_stamps: diagnostic cycle stamps
 
 template <int WAVES_M, int WAVES_N, int MT, int NT, int BK, bool OCC4 = false>
 static int launch_conv_gemm_fast(const ConvGemmParams &P, hipStream_t s) {
@@ -641,6 +656,14 @@ static int launch_conv_gemm_fast(const ConvGemmParams &P, hipStream_t s) {
                           : (uni ? (tap_inner ? conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, true, false, OCC4, true, true>
                                               : conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, true, false, OCC4, true, false>)
                                  : conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, true, false, OCC4, OCC4>);
+    ConvGemmParams Q = P;
+    if constexpr (OCC4) {   // in-kernel clock probe of the dominant instantiation (vq2_debug_set_stamps + VQ2_CLOCKPROBE=1)
+        static const int probe = tune("VQ2_CLOCKPROBE", 0);
+        if (probe && g_stamps && tap_inner && !P.relu_in) {
+            kern = conv_gemm_fast_kernel<WAVES_M, WAVES_N, MT, NT, BK, true, false, OCC4, true, true, true>;
+            Q.stamps = g_stamps;
+        }
+    }
     allow_big_lds(kern, lds);
     dim3 grid(nwg);
     const char *name = "conv_gemm";
@@ -648,7 +671,7 @@ static int launch_conv_gemm_fast(const ConvGemmParams &P, hipStream_t s) {
         name = prof_label("conv_gemm<%dx%dx%d>|M=%d,N=%d,K=%d,k%d,s%d,ph%d", BM, BN, BK, P.M, P.Co, P.K, P.KH, P.stride,
                           P.phases);
     ProfScope prof(name, P.flops, P.bytes, s, BM == 128 && BN == 128);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, P);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, Q);
     return check_launch("conv_gemm_fast_kernel");
 }
 
@@ -1079,8 +1102,6 @@ static int launch_conv_c4(const ConvGemmParams &P, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3((tiles + Q.c4_tpw - 1) / Q.c4_tpw), dim3(256), 0, s, Q);
     return check_launch("conv_k4s2_c4_kernel");
 }
-
-static unsigned long long *g_stamps = nullptr;  // set by vq2_debug_set_stamps: diagnostic cycle stamps
 
 static int tune(const char *name, int dflt) {
     const char *v = getenv(name);
