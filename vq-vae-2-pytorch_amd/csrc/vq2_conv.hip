@@ -1108,6 +1108,12 @@ static int tune(const char *name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
+// vq2_debug_set_stamps without VQ2_CLOCKPROBE: the phase-stamp build of the older 128x128x32 kernel takes every launch
+static bool legacy_stamps() {
+    static const int probe = tune("VQ2_CLOCKPROBE", 0);
+    return g_stamps != nullptr && !probe;
+}
+
 static int run_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
     // Tile by output-channel count (GEMM N).  Chunk depth per tile measured on MI355X: the 128x128 tile is
     // register-bound at 2 waves/SIMD and prefers BK=32; the narrower tiles run 4+ waves/SIMD with BK=16.
@@ -1122,17 +1128,17 @@ static int run_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
                          (long)P.N * P.Hy * P.Wy * P.ldy < lim && (long)P.N * P.Hy * P.Wy * (P.ldm > P.ldr ? P.ldm : P.ldr) < lim &&
                          (long)P.Co * P.K * P.phases < lim;
     static const int c4k = tune("VQ2_C4", 1);
-    if (c4k && fast_ok && !g_stamps && conv_c4_ok(P)) return launch_conv_c4(P, s);
+    if (c4k && fast_ok && !legacy_stamps() && conv_c4_ok(P)) return launch_conv_c4(P, s);
     static const int subpix = tune("VQ2_SUBPIX", 1);
     const long big = 0x7F000000L / 4;   // the patch kernel's out-of-range sentinel must stay above every tensor
     // (a launch of <= 256 workgroups with a short depth is better off with the 64-row GEMM tiles: measured)
     const long sp_wgs = (long)P.N * ((P.W + sp::TW - 1) / sp::TW) * ((P.H + sp::TH - 1) / sp::TH) * (P.Co / 64);
-    if (fast_ok && !g_stamps && subpix && P.phases == 4 && P.Co % 64 == 0 && P.Ci % 16 == 0 && P.K == 4 * P.Ci &&
+    if (fast_ok && !legacy_stamps() && subpix && P.phases == 4 && P.Co % 64 == 0 && P.Ci % 16 == 0 && P.K == 4 * P.Ci &&
         (sp_wgs >= 512 || P.K >= 512) &&
         (long)P.N * P.H * P.W * P.ldx < big && (long)P.N * P.Hy * P.Wy * P.ldy < big &&
         (long)P.N * P.Hy * P.Wy * (P.ldm > P.ldr ? P.ldm : P.ldr) < big)
         return launch_subpixel(P, s);
-    if (fast_ok && !g_stamps) {
+    if (fast_ok && !legacy_stamps()) {
         static const int t32 = tune("VQ2_T32", 1), tk = tune("VQ2_TSHORTK", 0), t64 = tune("VQ2_T64", 0),
                          tsm = tune("VQ2_TSM", 1);
         if (small_m && wgs128 < 400 && P.Co > 32) {
@@ -1182,7 +1188,7 @@ static int run_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
     }
     if (P.Co > 64) {
         if (bk128 == 16) return launch_conv_gemm<2, 2, 2, 2, 16>(P, s);
-        if (g_stamps) { ConvGemmParams Q = P; Q.stamps = g_stamps; return launch_conv_gemm<2, 2, 2, 2, 32, true>(Q, s); }
+        if (legacy_stamps()) { ConvGemmParams Q = P; Q.stamps = g_stamps; return launch_conv_gemm<2, 2, 2, 2, 32, true>(Q, s); }
         return launch_conv_gemm<2, 2, 2, 2, 32>(P, s);                     // 128 x 128
     }
     if (P.Co > 32) {
