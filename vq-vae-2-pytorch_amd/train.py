@@ -47,6 +47,15 @@ class Stage1Trainer:
         self.scheduler = None
         if sched == "cycle":  # train_vqvae.py:188-195
             self.scheduler = CycleScheduler(self.optimizer, lr, n_iter=n_iter, momentum=None, warmup_proportion=0.05)
+        # Stream priorities: the step's main chain should win every CU slot it can use, the side streams (small weight
+        # gradients, EMA statistics, early slab reduction, collectives) only what it leaves idle -- mostly the tails of
+        # its launches.  HIP knows two levels (0 and -1 = high), so the trainer installs a HIGH-priority stream as this
+        # thread's current stream, once (ordered after the work already queued on the previous one), and creates its
+        # side streams at the default priority: 6.78 -> 6.74 ms per step.  VQ2_MAIN_PRIO=0 leaves the current stream alone.
+        if os.environ.get("VQ2_MAIN_PRIO", "1") != "0" and torch.cuda.current_stream().priority == 0:
+            hp = torch.cuda.Stream(priority=-1)
+            hp.wait_stream(torch.cuda.current_stream())
+            torch.cuda.set_stream(hp)
         # this trainer's backward-pass state hangs on ITS parameters (no process-global state)
         wgrad_stream = torch.cuda.Stream() if os.environ.get("VQ2_WGRAD_STREAM", "1") != "0" else None
         self.ctx = ops.StepContext(wgrad_stream)
