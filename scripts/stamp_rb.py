@@ -16,12 +16,15 @@ t0 = time.time()
 while time.time() - t0 < 2.0:      # settle the clock first (scripts/clock_probe.py)
     for _ in range(20): run()
     torch.cuda.synchronize()
-buf = torch.zeros(128, dtype=torch.int64, device=dev)
+buf = torch.zeros(256, dtype=torch.int64, device=dev)
 lib.vq2_debug_set_rb_stamps(C.c_void_p(buf.data_ptr()))
 run()
 torch.cuda.synchronize()
 lib.vq2_debug_set_rb_stamps(None)
-allt = buf.cpu().view(2, 2, 4, 8)
+allt = buf.cpu()[:128].view(2, 2, 4, 8)
+fine = buf.cpu()[128:160].view(2, 4, 4)
+if int(fine.sum()):
+    print('forward kernel, slices 1..7 of wave 0 (VQ2_RB_FINE build): store / issue / mfma / barrier cycles per slice:', [round(v / 7) for v in fine[0, 0].tolist()])
 for kern, names in ((1, ["start->slice0 staged", "stage 1 (8 slices)", "r write", "stage 2", "epilogue"]),
                     (0, ["start->A0 staged", "phase A", "dh write + tap0", "phase B", "epilogue"])):
   t = allt[kern]

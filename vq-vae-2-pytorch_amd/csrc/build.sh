@@ -1,6 +1,7 @@
 #!/bin/bash
 # Build libvq2.so (gfx950 only) in-tree next to the Python package.
 set -euo pipefail
+trap 'echo "build.sh: FAILED (see the compiler messages above or csrc/_obj/*.res)" >&2' ERR
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="${VQ2_OUT:-$HERE/../libvq2.so}"     # VQ2_OUT + VQ2_OBJ + VQ2_EXTRA_FLAGS: A/B variant builds (scripts/build_variant.sh)
 OBJ="${VQ2_OBJ:-$HERE/_obj}"

@@ -28,6 +28,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace rb {
 constexpr bool WRITE_AFTER = VQ2_RB_WRITE_AFTER != 0;
+#ifndef VQ2_RB_INTERLEAVE
+#define VQ2_RB_INTERLEAVE 1
+#endif
+constexpr bool INTERLEAVE = VQ2_RB_INTERLEAVE != 0;   // staging instructions woven into the MFMA stream (forward kernel)
 constexpr unsigned RSRC_FLAGS = 0x00020000;
 constexpr int OOB = 0x7F000000;   // >= num_records of every descriptor (tensors are checked to be smaller), and
                                   // OOB + any in-tensor slice offset does not wrap
@@ -173,6 +177,21 @@ __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const ResFwdParams
     // hit the 16-byte LDS slots exactly like 32 consecutive rows do -- conflict-free ds_read_b128 for every tap.
     const int a_frag = ((2 * wq + (l31 >> 4)) * PW + (l31 < 16 ? l31 : ((l31 + 14) & 15))) * LDK + fk;
     const int b_frag = l31 * LDK + fk;
+    // Staging INSIDE the MFMA stream (round 3).  Fine stamps of a slice iteration (VQ2_RB_FINE build): 4,651 cycles of
+    // MFMAs (72 x 64: the chain itself is perfect), but 909 cycles to ISSUE the eight buffer loads of the slice after next
+    // and 525 for the eight LDS stores of the next one, all in front of the first MFMA -- a quarter of the iteration with an
+    // idle matrix pipe when the wave is alone on its SIMD.  A vector-memory or LDS-store instruction issued right behind an
+    // MFMA costs nothing (the MFMA executes for 64 cycles): MODE 1 stores slice s+1 from the registers one LDS store per
+    // MFMA group (groups 0..7) and requests slice s+2 one load per group (groups 8..15); MODE 2 (last slice) spreads the
+    // stage-2 prefetch the same way.
+    auto stage_one_store = [&](int buf, const Slice &r, int j) {
+        if (j < A_LD) *reinterpret_cast<float4 *>(As + buf * A_FLOATS + st_off + j * (NT / 4) * LDK) = relu4(u4_as_f4(r.a[j]));
+        else *reinterpret_cast<float4 *>(Bs + buf * B_FLOATS + st_off + (j - A_LD) * (NT / 4) * LDK) = u4_as_f4(r.b[j - A_LD]);
+    };
+    auto stage_one_load = [&](int s, Slice &r, int j) {
+        if (j < A_LD) r.a[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, a_off[j], s * CS * 4, 0);
+        else r.b[j - A_LD] = __builtin_amdgcn_raw_buffer_load_b128(rw1, b_off[j - A_LD], s * CS * 4, 0);
+    };
     auto compute = [&](int buf) {
         const float *a0 = As + buf * A_FLOATS + a_frag;
         const float *b0 = Bs + buf * B_FLOATS + b_frag;
@@ -222,6 +241,59 @@ __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const ResFwdParams
     // requested at once, then the 72 MFMAs of slice s -- the barrier follows them directly (no load wait and no LDS
     // stores between the last MFMA of one slice and the first of the next).  Slices 0 and 1 are requested back to back
     // into two register sets, so the peeled first iteration does not wait for a request it has just made.
+    // compute(buf) with the staging of slice s+1 (store) and s+2 (load) woven in; do_store / do_load are uniform
+    auto stage2_load = [&](int i) {      // one of the 16 + 64 loads of stage2_prefetch
+        constexpr int NW2 = NJ * (CM / 8);
+        if (i < NW2) {
+            const int j = i / (CM / 8), k8 = i % (CM / 8);
+            w2f[j][k8] = u4_as_f4(__builtin_amdgcn_raw_buffer_load_b128(rw2, ((j * 32 + l31) * CM + fk + 8 * k8) * 4, 0, 0));
+        } else if (i < NW2 + NJ * 16) {
+            const int j = (i - NW2) / 16, r = (i - NW2) % 16;
+            acc2[j][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xoff[r] + j * 128, 0, 0));
+        }
+    };
+    auto compute_staged = [&](int buf, int s, Slice &r, bool do_store, bool do_load, bool do_stage2) {
+        const float *a0 = As + buf * A_FLOATS + a_frag;
+        const float *b0 = Bs + buf * B_FLOATS + b_frag;
+        constexpr int NP = 9 * (CS / 8);
+        constexpr int NST = A_LD + B_LD;
+        static_assert(2 * NST <= NP, "stores then loads fit in the MFMA groups of one slice");
+        float4 fa[2], fb[2];
+        fa[0] = *reinterpret_cast<const float4 *>(a0);
+        fb[0] = *reinterpret_cast<const float4 *>(b0);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int cur = p & 1, nxt = cur ^ 1;
+            if (p + 1 < NP) {
+                const int tap = (p + 1) / (CS / 8), k8 = (p + 1) % (CS / 8);
+                fa[nxt] = *reinterpret_cast<const float4 *>(a0 + ((tap / 3) * PW + (tap % 3)) * LDK + 8 * k8);
+                fb[nxt] = *reinterpret_cast<const float4 *>(b0 + tap * 32 * LDK + 8 * k8);
+            }
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].x, fb[cur].x, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].y, fb[cur].y, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].z, fb[cur].z, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].w, fb[cur].w, acc1, 0, 0, 0);
+            if (p < NST) { if (do_store) stage_one_store(buf ^ 1, r, p); }
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // next pair's two LDS reads first ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // ... then this pair's MFMAs
+            if (p < NST) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);          // ... one LDS store behind them
+            if (p >= NST && p < 2 * NST && do_load) {
+                // (a group barrier does not hold a buffer load in place -- hipcc sinks all eight to the end of the slice,
+                //  where their issue is exposed again; a full scheduling fence on either side does)
+                __builtin_amdgcn_sched_barrier(0);
+                stage_one_load(s + 2, r, p - NST);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (do_stage2) {     // last slice: the 80 loads stage 2 needs, five per MFMA group
+                constexpr int PER = (NJ * (CM / 8) + NJ * 16 + NP - 1) / NP;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < PER; ++q) stage2_load(p * PER + q);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
     Slice R0, R1;
     issue_loads(0, R0);
     issue_loads(1, R1);
@@ -241,23 +313,51 @@ __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const ResFwdParams
             for (int r = 0; r < 16; ++r)
                 acc2[j][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xoff[r] + j * 128, 0, 0));
     };
-    if (WRITE_AFTER) {
+    if (WRITE_AFTER && INTERLEAVE) {
+        // slice 0: the registers R1 hold slice 1 (requested up front), R0 is free for slice 2
+        store_slice(1, R1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_staged(0, 0, R0, false, true, false);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        for (int s = 1; s < NS; ++s) {
+            const int buf = s & 1;
+            __builtin_amdgcn_sched_barrier(0);
+            compute_staged(buf, s, R0, s + 1 < NS, s + 2 < NS, s + 1 == NS);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+        }
+    } else if (WRITE_AFTER) {
         store_slice(1, R1);
         issue_loads(2, R0);
         __builtin_amdgcn_sched_barrier(0);   // the fetches must be in flight BEFORE the 72 MFMAs, not sunk behind them
         compute(0);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
+#ifdef VQ2_RB_FINE   // diagnostic variant build (scripts/build_variant.sh fine -DVQ2_RB_FINE): where a slice iteration goes
+        unsigned long long f_store = 0, f_issue = 0, f_mfma = 0, f_bar = 0;
+#define VQ2_FT(acc, stmt) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); \
+                            stmt; __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+                            acc += __builtin_amdgcn_s_memtime() - t0_; }
+#else
+#define VQ2_FT(acc, stmt) { stmt; }
+#endif
         for (int s = 1; s < NS; ++s) {
             const int buf = s & 1;
-            if (s + 1 < NS) store_slice(buf ^ 1, R0);
-            if (s + 2 < NS) issue_loads(s + 2, R0);
-            else if (s + 1 == NS) stage2_prefetch();
+            VQ2_FT(f_store, if (s + 1 < NS) store_slice(buf ^ 1, R0))
+            VQ2_FT(f_issue, if (s + 2 < NS) issue_loads(s + 2, R0); else if (s + 1 == NS) stage2_prefetch())
             __builtin_amdgcn_sched_barrier(0);
-            compute(buf);
+            VQ2_FT(f_mfma, compute(buf))
             __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
+            VQ2_FT(f_bar, __syncthreads())
         }
+#undef VQ2_FT
+#ifdef VQ2_RB_FINE
+        if (stamp_slot >= 0 && lane == 0) {
+            unsigned long long *fs = P.stamps + 64 + (stamp_slot * 4 + wq) * 4;   // behind the 64 coarse stamp words
+            fs[0] = f_store; fs[1] = f_issue; fs[2] = f_mfma; fs[3] = f_bar;
+        }
+#endif
     } else {   // write-before-barrier order: slice s+1 is requested in front of the MFMAs of slice s and stored behind them
         __builtin_amdgcn_sched_barrier(0);
         compute(0);
@@ -699,7 +799,7 @@ static void rb_dephase(int grid, int bwd, int *cycles, int *first_round) {
 }
 
 static unsigned long long *g_rb_stamps = nullptr, *g_rb_stamps_fwd = nullptr;
-// buf[64]: backward kernel; buf + 64 (another 64 words): forward kernel
+// buf[64]: backward kernel; buf + 64 (another 64 words): forward kernel (+ 32 more in the VQ2_RB_FINE diagnostic build)
 extern "C" int vq2_debug_set_rb_stamps(unsigned long long *buf) { g_rb_stamps = buf; g_rb_stamps_fwd = buf ? buf + 64 : nullptr; return VQ2_OK; }
 
 extern "C" int vq2_resblock_supported(int32_t C, int32_t Cm) { return (C == vq2::rb::CC && Cm == vq2::rb::CM) ? 1 : 0; }
