@@ -235,6 +235,9 @@ __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const ResFwdParams
     }
     f32x16 acc2[NJ];     // starts as the skip path x (vqvae.py:94); the 1x1 GEMM accumulates on top
     float4 w2f[NJ][CM / 8];   // this lane's B fragments of the 1x1 weight, straight from L2 (16 KB panel, no LDS trip)
+    float b1v = 0.f, b2v[NJ];   // this lane's bias values (requested with the stage-2 prefetch, not when they are needed)
+    const __amdgpu_buffer_rsrc_t rb1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.b1), 0, CM * 4, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rb2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.b2), 0, CC * 4, RSRC_FLAGS);
 
     // Pipeline (one barrier per slice): the registers hold slice s+1 when iteration s begins (requested a whole MFMA
     // phase earlier); it goes to the LDS buffer that every wave finished reading before the last barrier, slice s+2 is
@@ -250,6 +253,11 @@ __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const ResFwdParams
         } else if (i < NW2 + NJ * 16) {
             const int j = (i - NW2) / 16, r = (i - NW2) % 16;
             acc2[j][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xoff[r] + j * 128, 0, 0));
+        } else if (i == NW2 + NJ * 16) {
+            b1v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb1, l31 * 4, 0, 0));
+        } else if (i <= NW2 + NJ * 16 + NJ) {
+            const int j = i - (NW2 + NJ * 16 + 1);
+            b2v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb2, (j * 32 + l31) * 4, 0, 0));
         }
     };
     auto compute_staged = [&](int buf, int s, Slice &r, bool do_store, bool do_load, bool do_stage2) {
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const ResFwdParams
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (do_stage2) {     // last slice: the 80 loads stage 2 needs, five per MFMA group
-                constexpr int PER = (NJ * (CM / 8) + NJ * 16 + NP - 1) / NP;
+                constexpr int PER = (NJ * (CM / 8) + NJ * 16 + 1 + NJ + NP - 1) / NP;
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < PER; ++q) stage2_load(p * PER + q);
@@ -312,6 +320,9 @@ __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const ResFwdParams
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 acc2[j][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xoff[r] + j * 128, 0, 0));
+        b1v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb1, l31 * 4, 0, 0));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b2v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb2, (j * 32 + l31) * 4, 0, 0));
     };
     if (WRITE_AFTER && INTERLEAVE) {
         // slice 0: the registers R1 hold slice 1 (requested up front), R0 is free for slice 2
@@ -376,56 +387,68 @@ __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const ResFwdParams
     }
     stamp(2);
     // every wave is past its last fragment read: the staging buffers may be overwritten
-    {   // r = relu(acc1 + b1): to LDS for stage 2 and to HBM for the backward pass
-        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(P.r, 0, npix * P.ldr * 4, RSRC_FLAGS);
-        const float bv = P.b1[l31];
+    // r = relu(acc1 + b1): to LDS for stage 2 now; its 16 stores to HBM (the backward pass needs r) are issued behind the
+    // MFMAs of stage 2's first column block, and the 16 stores of every finished column block behind the MFMAs of the
+    // next one (column block OUTER, k INNER: a block is complete after 16 MFMAs) -- only the last block's stores are
+    // exposed.  The biases were requested with the stage-2 prefetch.
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(P.r, 0, npix * P.ldr * 4, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(P.y, 0, npix * P.ldy * 4, RSRC_FLAGS);
+    float rv[16];
+    int roff[16];
+    {
         const int ldr4 = P.ldr * 4;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = rowq + (r & 3) + 8 * (r >> 2);
             const int pix = __shfl(pix_lane, row, 64);
-            const float v = relu1(acc1[r] + bv);
-            Rs[(32 * wq + row) * LDR + l31] = v;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rr, pix >= 0 ? pix * ldr4 + l31 * 4 : OOB, 0, 0);
+            rv[r] = relu1(acc1[r] + b1v);
+            Rs[(32 * wq + row) * LDR + l31] = rv[r];
+            roff[r] = pix >= 0 ? pix * ldr4 + l31 * 4 : OOB;
         }
     }
     // a wave reads back only the 32 rows it wrote itself (LDS operations of one wave complete in order): no barrier
-
     stamp(3);
     // ---- stage 2: 1x1 conv on the r tile, on top of x + b2
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const float bv = P.b2[j * 32 + l31];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[j][r] += bv;
-    }
+    const int relu_floor_bits = P.relu_out ? 0 : (int)0x80000000;
     {
         const float *a = Rs + (32 * wq + l31) * LDR + fk;
+        float4 fa[CM / 8];
 #pragma unroll
-        for (int k8 = 0; k8 < CM / 8; ++k8) {
-            const float4 fa = *reinterpret_cast<const float4 *>(a + 8 * k8);
+        for (int k8 = 0; k8 < CM / 8; ++k8) fa[k8] = *reinterpret_cast<const float4 *>(a + 8 * k8);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[j][r] += b2v[j];
+#pragma unroll
+            for (int k8 = 0; k8 < CM / 8; ++k8) {
                 const float4 fb = w2f[j][k8];
-                acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc2[j], 0, 0, 0);
-                acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc2[j], 0, 0, 0);
-                acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc2[j], 0, 0, 0);
-                acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc2[j], 0, 0, 0);
+                acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k8].x, fb.x, acc2[j], 0, 0, 0);
+                acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k8].y, fb.y, acc2[j], 0, 0, 0);
+                acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k8].z, fb.z, acc2[j], 0, 0, 0);
+                acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k8].w, fb.w, acc2[j], 0, 0, 0);
+                // four stores of the PREVIOUS block (or of r) behind these four MFMAs
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = 4 * k8 + q;
+                    if (j == 0) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rv[r]), rr, roff[r], 0, 0);
+                    } else {
+                        const float v = relu_floor(acc2[j - 1][r], relu_floor_bits);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, yoff[r] + (j - 1) * 128, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
     stamp(4);
-    // ---- epilogue: optional trailing ReLU (vqvae.py:122,144), store
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(P.y, 0, npix * P.ldy * 4, RSRC_FLAGS);
-    const bool relu_out = P.relu_out != 0;
+    // ---- epilogue: optional trailing ReLU (vqvae.py:122,144) and store of the last column block
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v = acc2[j][r];
-            v = relu_floor(v, relu_out ? 0 : (int)0x80000000);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, yoff[r] + j * 128, 0, 0);
-        }
+    for (int r = 0; r < 16; ++r) {
+        const float v = relu_floor(acc2[NJ - 1][r], relu_floor_bits);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, yoff[r] + (NJ - 1) * 128, 0, 0);
+    }
     if (stamp_slot >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp(5);
 }
