@@ -740,41 +740,92 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_data_kernel(const ResBwdP
     }
     float mtmp[16], gres[4][16];
     unsigned mbits[2] = {0u, 0u};
+    auto issue_b_one = [&](int tap, int j) {
+        rwb[j] = __builtin_amdgcn_raw_buffer_load_b128(rw1, wb_goff + j * 32 * 9 * CM * 4, tap * CM * 4, 0);
+    };
+    auto store_b_one = [&](int buf, int j) {
+        *reinterpret_cast<float4 *>(Wb + buf * WB_FLOATS + st8 + j * 32 * LDA) = u4_as_f4(rwb[j]);
+    };
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int buf = tap & 1;
-        if (WRITE_AFTER) {
-            if (tap + 1 < 9) store_b(buf ^ 1);
-            if (tap + 2 < 9) issue_b(tap + 2);
-        } else if (tap + 1 < 9) {
-            issue_b(tap + 1);
-        }
-        if (tap < 4) {
+        if (!(WRITE_AFTER && INTERLEAVE)) {
+            if (WRITE_AFTER) {
+                if (tap + 1 < 9) store_b(buf ^ 1);
+                if (tap + 2 < 9) issue_b(tap + 2);
+            } else if (tap + 1 < 9) {
+                issue_b(tap + 1);
+            }
+            if (tap < 4) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
-                mtmp[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, poff[q], tap * 128, 0));
-        }
-        if (tap >= 5) {
+                for (int q = 0; q < 16; ++q)
+                    mtmp[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, poff[q], tap * 128, 0));
+            }
+            if (tap >= 5) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
-                gres[tap - 5][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                    rg, SAME_LD ? poff[q] : (pixr[SAME_LD ? 0 : q] >= 0 ? pixr[SAME_LD ? 0 : q] * P.ldg * 4 + l31 * 4 : OOB),
-                    (tap - 5) * 128, 0));
+                for (int q = 0; q < 16; ++q)
+                    gres[tap - 5][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                        rg, SAME_LD ? poff[q] : (pixr[SAME_LD ? 0 : q] >= 0 ? pixr[SAME_LD ? 0 : q] * P.ldg * 4 + l31 * 4 : OOB),
+                        (tap - 5) * 128, 0));
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         {
             const float *a = Dh + a_frag + ((tap / 3) * PW + (tap % 3)) * LDA;
             const float *b = Wb + buf * WB_FLOATS + l31 * LDA + fk;
+            if (WRITE_AFTER && INTERLEAVE) {
+                // 16 groups of four MFMAs (k8 outer, column block inner); the fragments of group g+1 are requested before
+                // the MFMAs of group g, and behind every group sit (between scheduling fences, see the forward kernel):
+                //   groups 0-3    one LDS store of the NEXT tap's panel (registers requested during the previous tap)
+                //   groups 4-7    one load of the panel after next
+                //   groups 0-7    two mask loads (taps 0-3: they have eight groups to land before the fold below)
+                //   groups 0-15   one skip-gradient load (taps 5-8: consumed in the epilogue only)
+                float4 fa[2], fb[2];
+                fa[0] = *reinterpret_cast<const float4 *>(a);
+                fb[0] = *reinterpret_cast<const float4 *>(b);
 #pragma unroll
-            for (int k8 = 0; k8 < CM / 8; ++k8) {
-                const float4 fa = *reinterpret_cast<const float4 *>(a + 8 * k8);
+                for (int g = 0; g < 16; ++g) {
+                    const int k8 = g >> 2, j = g & 3, cur = g & 1, nxt = cur ^ 1, ca = k8 & 1;
+                    if (g + 1 < 16) {
+                        const int k8n = (g + 1) >> 2, jn = (g + 1) & 3;
+                        fb[nxt] = *reinterpret_cast<const float4 *>(b + jn * 32 * LDA + 8 * k8n);
+                        if (jn == 0) fa[k8n & 1] = *reinterpret_cast<const float4 *>(a + 8 * k8n);
+                    }
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ca].x, fb[cur].x, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ca].y, fb[cur].y, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ca].z, fb[cur].z, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ca].w, fb[cur].w, acc[j], 0, 0, 0);
+                    if (g + 1 < 16) {     // next group's LDS reads first, then this group's MFMAs
+                        if (((g + 1) & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g < 4 && tap + 1 < 9) store_b_one(buf ^ 1, g);
+                    if (g >= 4 && g < 8 && tap + 2 < 9) issue_b_one(tap + 2, g - 4);
+                    if (tap < 4 && g < 8) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 fb = *reinterpret_cast<const float4 *>(b + j * 32 * LDA + 8 * k8);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc[j], 0, 0, 0);
+                        for (int q = 2 * g; q < 2 * g + 2; ++q)
+                            mtmp[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, poff[q], tap * 128, 0));
+                    }
+                    if (tap >= 5)
+                        gres[tap - 5][g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                            rg, SAME_LD ? poff[g] : (pixr[SAME_LD ? 0 : g] >= 0 ? pixr[SAME_LD ? 0 : g] * P.ldg * 4 + l31 * 4 : OOB),
+                            (tap - 5) * 128, 0));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int k8 = 0; k8 < CM / 8; ++k8) {
+                    const float4 fa = *reinterpret_cast<const float4 *>(a + 8 * k8);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float4 fb = *reinterpret_cast<const float4 *>(b + j * 32 * LDA + 8 * k8);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc[j], 0, 0, 0);
+                    }
                 }
             }
         }
