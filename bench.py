@@ -8,7 +8,7 @@ One "step" = forward + MSE+0.25*latent loss + backward + EMA codebook update + A
 synthetic 256x256 images already resident in HBM (BASELINE.json configs[1]: default two-level
 VQVAE, batch 32 per GPU; weak scaling: every rank keeps 32 images, one packed RCCL all-reduce per
 step).  Rank 0 prints ONE JSON line.  The line also carries
-  roofline     -- the dominant kernel (fp32-MFMA implicit-GEMM conv, csrc/vq2_conv.hip): algorithmic
+  roofline     -- the dominant kernel (fp32-MFMA 3x3 conv, csrc/vq2_wino.hip / vq2_conv.hip): algorithmic
                   FLOPs of its launches / their HIP-event time, measured live in the timed region
   cpu_baseline -- the CPU oracle (PyTorch-CPU restatement of the reference graph, kind "port") timed on
                   this box's host cores on a bounded sample (N=1, rank 0 only)
@@ -221,7 +221,7 @@ def main():
             f = fam.setdefault(k.split("|")[0], {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             for kk in f:
                 f[kk] += v[kk]
-        conv = {k: v for k, v in fam.items() if k.startswith("conv_gemm")}
+        conv = {k: v for k, v in fam.items() if k.startswith(("conv_gemm", "conv_wino3"))}
         if conv:
             dom = max(conv, key=lambda k: conv[k]["ms"])
             r = conv[dom]
@@ -241,6 +241,12 @@ def main():
                     "traffic_source": tsrc, "algorithmic_bytes_per_launch": round(r["bytes"] / r["launches"]),
                     "launches_per_step": r["launches"] // max(sampled, 1), "sampled_steps": sampled,
                     "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2)}
+            if dom.startswith("conv_wino3"):
+                # `achieved` counts the ALGORITHMIC FLOPs of the 3x3 convolution (18 per output and channel pair); the
+                # Winograd F(2,3) form executes 2/3 of them on the matrix pipe (csrc/vq2_wino.hip), so the fraction of
+                # the fp32 MFMA peak the hardware actually sustains is executed_frac
+                roof["executed_tflops"] = round(ach * 2.0 / 3.0, 2)
+                roof["executed_frac"] = round(ach * 2.0 / 3.0 / PEAK_F32_TFLOPS, 4)
         line = {
             "metric": "images/sec VQVAE_Deep 256px train step (not the BASELINE metric)" if deep else
                       "images/sec VQ-VAE-2 256px train step", "value": round(value, 2), "unit": "images/s",

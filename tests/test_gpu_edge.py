@@ -106,6 +106,64 @@ def test_channel_slices_and_fused_flags(amd):
     close(dx, xr.grad.permute(0, 2, 3, 1) + wide_in[..., 0:12].cpu())
 
 
+def _launched(amd, fn):
+    """Run fn with every instrumented launch bracketed; returns (result, kernel labels seen)."""
+    import ctypes
+    lib = amd._lib.lib
+    lib.vq2_prof_enable(1)
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+    finally:
+        lib.vq2_prof_enable(0)
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib.vq2_prof_report(buf, len(buf))
+    return out, [ln.split()[0] for ln in buf.value.decode().splitlines()]
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 64, 64, 128), (1, 4, 128, 72, 256), (3, 2, 64, 128, 128)])
+def test_winograd_rows_conv_forward_and_data_gradient(amd, shape):
+    """3x3 stride-1 convolutions with >= 64 input channels, whole 128-channel output tiles and rows of whole 64-pixel
+    segments run as F(2,3) Winograd along the rows (csrc/vq2_wino.hip): forward with ReLU-in / bias / residual / ReLU-out
+    through channel slices, data gradient with the ReLU mask and the skip gradient, against fp64 torch on the CPU.  The
+    image border (zero padding on all four sides) and the seams between 64-pixel segments are part of every case."""
+    from vqvae2_amd import ops
+    dev = torch.device("cuda:0")
+    n, h, w, ci, co = shape
+    tag = "wino%dx%dx%d" % (h, w, ci)
+    wide_in = t(rng.normal(9, tag + ".in", (n, h, w, ci + 8))).to(dev)
+    x = wide_in[..., 4:4 + ci]                                # pixel stride ci + 8
+    wide_out = torch.full((n, h, w, co + 8), 7.0, device=dev)
+    res = t(rng.normal(9, tag + ".res", (n, h, w, co))).to(dev)
+    wt = t(rng.uniform(9, tag + ".w", (co, ci, 3, 3), -0.1, 0.1)).to(dev)
+    b = t(rng.uniform(9, tag + ".b", (co,), -1, 1)).to(dev)
+    spec = ops.ConvSpec(False, ci, co, 3, 1, 1)
+    y, seen = _launched(amd, lambda: ops.conv_forward(spec, x, wt, b, ops.VQ2_RELU_IN | ops.VQ2_RELU_OUT, residual=res,
+                                                      out=wide_out[..., 4:4 + co]))
+    assert any(k.startswith("conv_wino3") for k in seen), seen
+    x64 = x.permute(0, 3, 1, 2).cpu().double()
+    ref = F.relu(F.conv2d(F.relu(x64), wt.cpu().double(), b.cpu().double(), padding=1)
+                 + res.permute(0, 3, 1, 2).cpu().double()).permute(0, 2, 3, 1)
+    scale = float(ref.abs().max())
+    close(y.double(), ref, rtol=0, atol=5e-6 * scale, what=tag + ".y")       # fp32 rounding of a depth-9*ci sum
+    assert float(wide_out[..., :4].min()) == 7.0 and float(wide_out[..., 4 + co:].max()) == 7.0
+    y2, seen = _launched(amd, lambda: ops.conv_forward(spec, x, wt, None, 0))   # no bias, no ReLU, dense output
+    assert any(k.startswith("conv_wino3") for k in seen), seen
+    ref2 = F.conv2d(x64, wt.cpu().double(), None, padding=1).permute(0, 2, 3, 1)
+    close(y2.double(), ref2, rtol=0, atol=5e-6 * float(ref2.abs().max()), what=tag + ".y2")
+    # data gradient (the same kernel on the flipped panel) needs whole 128-channel tiles of the INPUT channel count
+    if ci % 128 == 0:
+        dy = t(rng.normal(9, tag + ".dy", (n, h, w, co))).to(dev)
+        dx_wide = torch.zeros((n, h, w, ci + 8), device=dev)
+        dx, seen = _launched(amd, lambda: ops.conv_dgrad(spec, (n, h, w, ci), dy, wt, mask=x, residual=wide_in[..., 0:ci],
+                                                          out=dx_wide[..., 4:4 + ci]))
+        assert any(k.startswith("conv_wino3") for k in seen), seen
+        xr = x64.clone().requires_grad_(True)
+        F.conv2d(F.relu(xr), wt.cpu().double(), None, padding=1).backward(dy.permute(0, 3, 1, 2).cpu().double())
+        refg = xr.grad.permute(0, 2, 3, 1) + wide_in[..., 0:ci].cpu().double()
+        close(dx.double(), refg, rtol=0, atol=5e-6 * float(refg.abs().max()), what=tag + ".dx")
+
+
 def test_layout_conversion_generic_channels(amd):
     from vqvae2_amd import ops
     dev = torch.device("cuda:0")

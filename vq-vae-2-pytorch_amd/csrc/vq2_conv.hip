@@ -19,34 +19,12 @@
 //
 // ConvTranspose2d(k4,s2,p1) and the data-gradient of a stride-2 4x4 conv are the same
 // sub-pixel decomposition: 4 output phases, each a 2x2 stride-1 conv; blockIdx.z = phase.
-#include "vq2_common.h"
+#include "vq2_conv.h"
 #include <type_traits>
 #include <stdlib.h>
 
 namespace vq2 {
 
-struct ConvGemmParams {
-    const float *x;   // [N,H,W,ldx]
-    const float *w;   // [phases][Co][K]   (K = KH*KW*Ci, ci fastest)
-    const float *bias;  // [Co] or null
-    const float *mask;  // shape of y (pixel stride ldm) or null: y *= (mask > 0)
-    const float *res;   // shape of y (pixel stride ldr) or null: y += res
-    float *y;           // [N,Hy,Wy,ldy]
-    int N, H, W, Ci, ldx;
-    int Ho, Wo, Co, ldy;  // virtual output grid (rows of the GEMM) and channels
-    int KH, KW, stride, pad_h, pad_w;
-    int K, M;             // K = KH*KW*Ci, M = N*Ho*Wo
-    int phases;           // 1, or 4 for the sub-pixel transposed conv
-    int Hy, Wy;           // real output image size
-    int ldm, ldr;
-    int relu_in, relu_out;
-    int mask_after;       // apply the mask to (acc + residual) instead of to acc alone
-    int nbias;            // bias has nbias entries (real output channels)
-    int c4_tpw;           // conv_k4s2_c4_kernel: tiles per workgroup
-    int ci_real;          // real input channels (<= Ci; the rest are zero padding), 0 = Ci
-    double flops, bytes;  // algorithmic work of this launch (for the profiler only)
-    unsigned long long *stamps;  // diagnostic build only (STAMP): per-phase cycle totals of workgroup 0
-};
 
 // BK = depth of one staged chunk; LDS rows are padded to BK+4 floats (144 B / 80 B), which makes the
 // ds_read_b128 fragment reads conflict-free (16-byte slot index = row*9 resp. row*5 mod 16).
@@ -297,13 +275,6 @@ __global__ __launch_bounds__(256, (MT * NT == 4) ? (BK == 16 ? 3 : 2) : 1) void 
 //   * epilogue: 32-bit offsets, one add per element; sub-pixel phases share one division per tile row
 // Limits (checked by the launcher): KH*KW <= 32, every tensor < 2 GiB.
 static int tune(const char *name, int dflt);
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr int OOB = 0x7FFFFFF0;  // >= num_records of every descriptor: loads return 0, stores are dropped
-constexpr unsigned RSRC_FLAGS = 0x00020000;
-
-__device__ __forceinline__ float4 as_f4(u32x4 v) {
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
 
 // OCC4: four workgroups per CU (BK = 16, <= 128 VGPRs, exactly 40 KiB of LDS: the tap table is replaced by a
 // per-thread (kh, kw) counter) -- all 1,024 tiles of a 64x64-resolution layer are then resident at once: ONE
@@ -1129,6 +1100,7 @@ static int run_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
                          (long)P.Co * P.K * P.phases < lim;
     static const int c4k = tune("VQ2_C4", 1);
     if (c4k && fast_ok && !legacy_stamps() && conv_c4_ok(P)) return launch_conv_c4(P, s);
+    if (fast_ok && !legacy_stamps() && wino3_ok(P)) return launch_wino3(P, s);   // vq2_wino.hip
     static const int subpix = tune("VQ2_SUBPIX", 1);
     const long big = 0x7F000000L / 4;   // the patch kernel's out-of-range sentinel must stay above every tensor
     // (a launch of <= 256 workgroups with a short depth is better off with the 64-row GEMM tiles: measured)

@@ -1,0 +1,290 @@
+// 3x3 stride-1 pad-1 convolution (forward, and the data gradient, which is the same operation on the flipped
+// panel) as Winograd F(2,3) ALONG THE IMAGE ROWS, on the exact-fp32 matrix instruction.
+//
+// Two neighbouring output pixels of a row (a "column pair" t: columns 2t, 2t+1) share the four input columns
+// 2t-1 .. 2t+2.  With  V0 = d0 - d2, V1 = d1 + d2, V2 = d2 - d1, V3 = d1 - d3  (d = the four input columns, any row,
+// any channel) and  U0 = g0, U1 = g0 + g1 + g2, U2 = g0 - g1 + g2, U3 = g2  (g = the three taps of one kernel row):
+//     M_v = sum over kernel rows kh and input channels ci of  V_v[row + kh - 1][ci] * U_v[kh][ci][co]      v = 0..3
+//     y[2t]   = M0 + (M1 + M2) / 2          y[2t+1] = (M1 - M2) / 2 - M3
+// Four GEMMs of depth 3*Ci over HALF as many rows instead of one GEMM of depth 9*Ci: 12 multiplications per output
+// pair and channel pair instead of 18 -- 2/3 of the matrix instructions of the direct form (vq2_conv.hip), which is
+// what bounds this layer (0.87 of the fp32 MFMA peak there; 157 TFLOP/s is all the chip has).  Everything is still
+// fp32 with fp32 accumulation; the rounding differs from the direct sum the way any other summation order does
+// (measured against fp64: 1.5 - 2x the direct form's 2e-7 relative error; F(4,3) and the 2-D F(2x2,3x3) were not
+// taken: 16 accumulator sets per output tile do not fit the register file next to a 32x32 MFMA tile).
+//
+// Workgroup = TR image rows x TPW column pairs (64 pairs = 128 output pixels) x 128 output channels; wave (wm, wn) owns
+// 32 pairs x 32*NT channels for all four v (lane-local output transform).  Per 8-channel block the RAW halo patch
+// ((TR+2) x (2*TPW+2) pixels, ReLU applied) is staged once and serves the three kernel rows; a lane builds its four V
+// fragments from four patch reads.  The weight panel stays in the direct kernel's packed layout [co][(kh,kw,ci)]
+// (include/vq2.h: same ABI): the three taps of a kernel row are transformed while they are staged.
+#include "vq2_conv.h"
+
+#ifndef VQ2_WINO_EXP
+#define VQ2_WINO_EXP 0   // timing experiments (wrong results): 1 no loads in the loop, 2 no loads + no LDS stores, 3 no input
+#endif                   // transform, 4 no weight transform, 5 no barrier in the loop, 6 no output stores
+
+namespace vq2 {
+namespace wino {
+
+constexpr int TP = 64;             // column pairs per workgroup
+constexpr int BN = 128;            // output channels per workgroup
+constexpr int BK = 8, LDK = BK + 4;   // 48-byte LDS rows: conflict-free ds_read_b128 (vq2_conv.hip)
+constexpr int B_FLOATS = 4 * BN * LDK;
+
+template <int TPW, int NT>
+struct Geo {
+    static constexpr int NWN = 4 / NT, NTHR = 128 * NWN;
+    static constexpr int TR = TP / TPW, PR = TR + 2, PW = 2 * TPW + 2, NPX = PR * PW;
+    static constexpr int A_FLOATS = (NPX + 1) * LDK;          // + one dump row for the items past the patch
+    static constexpr int A_ITEMS = NPX * 2;                    // (pixel, 4-channel quad)
+    static constexpr int A_LD = (A_ITEMS + NTHR - 1) / NTHR;
+    static constexpr size_t LDS_BYTES = (size_t)2 * (A_FLOATS + B_FLOATS) * sizeof(float);
+};
+
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+template <int TPW, int NT, bool RELU_IN>
+__global__ __launch_bounds__(128 * (4 / NT), NT == 1 ? 4 : 2) void wino3_kernel(const ConvGemmParams P) {
+    using G = Geo<TPW, NT>;
+    constexpr int NWN = G::NWN, NTHR = G::NTHR, PW = G::PW, NPX = G::NPX, A_FLOATS = G::A_FLOATS, A_LD = G::A_LD;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                    // [2][A_FLOATS]   raw patch of one 8-channel block
+    float *Bs = smem + 2 * A_FLOATS;     // [2][4][BN][LDK] transformed taps of one (kernel row, channel block)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int ntn = P.Co / BN, tw = P.W / (2 * TPW), th = P.H / G::TR;
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = (vid % ntn) * BN;
+    const int sp = vid / ntn;
+    const int wb = sp % tw, hb = (sp / tw) % th, n = sp / (tw * th);
+    const int h0 = hb * G::TR, w0 = wb * 2 * TPW;
+
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x), 0, P.N * P.H * P.W * P.ldx * 4, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.w), 0, P.Co * P.K * 4, RSRC_FLAGS);
+
+    // ---- staging coordinates.  Patch items (pixel, quad): loads are UNCONDITIONAL -- an item outside the image or past
+    // the patch carries an offset beyond the descriptor's range (reads 0) and an LDS slot in the dump row.
+    int a_off[A_LD], a_dst[A_LD];
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+        const int it = tid + NTHR * j;
+        const bool ok = it < G::A_ITEMS;
+        const int px = ok ? (it >> 1) : 0, q = it & 1;
+        const int pr = px / PW, pc = px - pr * PW;
+        const int row = h0 - 1 + pr, col = w0 - 1 + pc;
+        const bool in = ok && (unsigned)row < (unsigned)P.H && (unsigned)col < (unsigned)P.W;
+        a_off[j] = in ? (((n * P.H + row) * P.W + col) * P.ldx + 4 * q) * 4 : (int)0x80000000;
+        a_dst[j] = (ok ? px : NPX) * LDK + 4 * q;
+    }
+    // weight items (co, quad): the first 256 threads
+    const bool role_b = (NTHR == 256) || tid < 256;
+    const int bco = (tid & 255) >> 1, bq = tid & 1;
+    const int b_off = ((n0 + bco) * P.K + 4 * bq) * 4;
+    const int b_dst = bco * LDK + 4 * bq;
+    const int ci4 = P.Ci * 4;
+
+    u32x4 ra[A_LD], rb[3];
+    auto load_b = [&](int kh, int cb) {
+        const int kb = (kh * 3 * P.Ci + cb) * 4;   // scalar
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) rb[kw] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_off + kb + kw * ci4, 0, 0);
+    };
+    auto store_b = [&](float *b) {
+        const float4 g0 = as_f4(rb[0]), g1 = as_f4(rb[1]), g2 = as_f4(rb[2]);
+        const float4 t = add4(g0, g2);
+        *reinterpret_cast<float4 *>(b + 0 * BN * LDK + b_dst) = g0;
+        *reinterpret_cast<float4 *>(b + 1 * BN * LDK + b_dst) = VQ2_WINO_EXP == 4 ? g1 : add4(t, g1);
+        *reinterpret_cast<float4 *>(b + 2 * BN * LDK + b_dst) = VQ2_WINO_EXP == 4 ? g1 : sub4(t, g1);
+        *reinterpret_cast<float4 *>(b + 3 * BN * LDK + b_dst) = g2;
+    };
+    auto store_a = [&](float *a, int j) {
+        const float4 v = as_f4(ra[j]);
+        *reinterpret_cast<float4 *>(a + a_dst[j]) = RELU_IN ? relu4(v) : v;
+    };
+
+    f32x16 acc[4][NT];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[v][j][r] = 0.f;
+
+    const int frag_row = lane & 31, frag_k = 4 * (lane >> 5);
+    const int pi = wm * 32 + frag_row;                 // this lane's column pair of the tile
+    const int pr_l = pi / TPW, pt_l = pi - pr_l * TPW;
+    const int lane_a = (pr_l * PW + 2 * pt_l) * LDK + frag_k;
+    const int lane_b = (wn * NT * 32 + frag_row) * LDK + frag_k;
+
+    auto compute = [&](const float *a, const float *b, int kh) {
+        const float *ap = a + lane_a + kh * PW * LDK;
+        const float4 d0 = *reinterpret_cast<const float4 *>(ap);
+        const float4 d1 = *reinterpret_cast<const float4 *>(ap + LDK);
+        const float4 d2 = *reinterpret_cast<const float4 *>(ap + 2 * LDK);
+        const float4 d3 = *reinterpret_cast<const float4 *>(ap + 3 * LDK);
+        float4 fb[4][NT];
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[v][j] = *reinterpret_cast<const float4 *>(b + (v * BN + j * 32) * LDK + lane_b);
+        float4 fv[4];
+        if (VQ2_WINO_EXP == 3) { fv[0] = d0; fv[1] = d1; fv[2] = d2; fv[3] = d3; } else {
+        fv[0] = sub4(d0, d2);
+        fv[1] = add4(d1, d2);
+        fv[2] = sub4(d2, d1);
+        fv[3] = sub4(d1, d3);
+        }
+#define VQ2_WINO_STEP(C)                                                                                          \
+    _Pragma("unroll") for (int v = 0; v < 4; ++v) _Pragma("unroll") for (int j = 0; j < NT; ++j)                  \
+        acc[v][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[v].C, fb[v][j].C, acc[v][j], 0, 0, 0);
+        VQ2_WINO_STEP(x) VQ2_WINO_STEP(y) VQ2_WINO_STEP(z) VQ2_WINO_STEP(w)
+#undef VQ2_WINO_STEP
+    };
+
+    // ---- prologue: patch of channel block 0, taps of (kh 0, block 0)
+    const int NCB = P.Ci / BK;
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, a_off[j], 0, 0);
+    load_b(0, 0);
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) store_a(As, j);
+    if (role_b) store_b(Bs);
+    __syncthreads();
+
+    // ---- main loop: chunk c = (channel block cbi, kernel row kh), kh innermost.  Behind the loads of chunk c+1 run the
+    // MFMAs of chunk c; the stores go to the other buffers; one barrier per chunk.
+    int c = 0;
+    for (int cbi = 0; cbi < NCB; ++cbi) {
+        const int cbn = (cbi + 1 < NCB) ? cbi + 1 : cbi;    // (the last block re-loads itself into the idle buffer)
+        const float *a_cur = As + (cbi & 1) * A_FLOATS;
+        float *a_nxt = As + ((cbi + 1) & 1) * A_FLOATS;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int nkh = (kh + 1) % 3;
+            const int ncb = (kh == 2) ? cbn : cbi;
+            if (VQ2_WINO_EXP != 1 && VQ2_WINO_EXP != 2) {
+                if (role_b) load_b(nkh, ncb * BK);
+                // the next block's patch: issued BEHIND the weight loads of kernel row 0 and stored a chunk later, so that an
+                // activation line that has to come from HBM has two chunks of time and never holds up the weight tile
+                // (loads return in order: waiting for a younger load waits for every older one)
+                if (kh == 0) {
+#pragma unroll
+                    for (int j = 0; j < A_LD; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, a_off[j] + cbn * BK * 4, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks the loads to just before their stores)
+            compute(a_cur, Bs + (c & 1) * B_FLOATS, kh);
+            __builtin_amdgcn_sched_barrier(0);
+            if (VQ2_WINO_EXP != 2) {
+                if (role_b) store_b(Bs + ((c + 1) & 1) * B_FLOATS);
+                if (kh == 1) {
+#pragma unroll
+                    for (int j = 0; j < A_LD; ++j) store_a(a_nxt, j);
+                }
+            }
+            if (VQ2_WINO_EXP != 5) __syncthreads();
+            ++c;
+        }
+    }
+
+    // ---- epilogue: output transform in registers, then the direct kernel's epilogue on two pixels per row
+    const int ybytes = P.N * P.Hy * P.Wy * 4;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(P.y, 0, ybytes * P.ldy, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rmk =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.mask ? P.mask : P.y), 0, P.mask ? ybytes * P.ldm : 0, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.res ? P.res : P.y), 0, P.res ? ybytes * P.ldr : 0, RSRC_FLAGS);
+    const bool has_mask = P.mask != nullptr, has_res = P.res != nullptr;
+    const bool mask_first = has_mask && !P.mask_after, mask_last = has_mask && P.mask_after;
+    const int colq = lane & 31, rowq = 4 * (lane >> 5);
+    const int ldy4 = P.ldy * 4, ldm4 = P.ldm * 4, ldr4 = P.ldr * 4;
+    const int relu_bits = P.relu_out ? 0 : (int)0x80000000;
+    // pixel of pair (wm * 32 + lane & 31), shared through ds_bpermute
+    const int pix_lane = ((n * P.H + h0 + pr_l) * P.W + w0 + 2 * pt_l);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int co = n0 + (wn * NT + j) * 32 + colq;
+        const float bv = (P.bias && co < P.nbias) ? P.bias[co] : 0.f;
+        const int co4 = co * 4;
+#pragma unroll
+        for (int rb4 = 0; rb4 < 16; rb4 += 4) {
+            int pix[8];
+            float mk[8], rs[8], val[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = rb4 + q;
+                const int rr = rowq + (r & 3) + 8 * (r >> 2);
+                const int p0 = __shfl(pix_lane, rr, 64);
+                pix[2 * q] = p0;
+                pix[2 * q + 1] = p0 + 1;
+                const float m0 = acc[0][j][r], m1 = acc[1][j][r], m2 = acc[2][j][r], m3 = acc[3][j][r];
+                val[2 * q] = m0 + 0.5f * (m1 + m2);
+                val[2 * q + 1] = 0.5f * (m1 - m2) - m3;
+            }
+            if (has_mask) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    mk[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rmk, pix[q] * ldm4 + co4, 0, 0));
+            }
+            if (has_res) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    rs[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, pix[q] * ldr4 + co4, 0, 0));
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float v = val[q] + bv;
+                if (mask_first) v = (mk[q] > 0.f) ? v : 0.f;
+                if (has_res) v += rs[q];
+                if (mask_last) v = (mk[q] > 0.f) ? v : 0.f;
+                v = relu_floor(v, relu_bits);
+                if (VQ2_WINO_EXP != 6 || v == 123.456f)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, pix[q] * ldy4 + co4, 0, 0);
+            }
+        }
+    }
+}
+
+template <int TPW, int NT>
+static int launch(const ConvGemmParams &P, hipStream_t s) {
+    using G = Geo<TPW, NT>;
+    auto kern = P.relu_in ? wino3_kernel<TPW, NT, true> : wino3_kernel<TPW, NT, false>;
+    allow_big_lds(kern, G::LDS_BYTES);
+    const unsigned nwg = (unsigned)(P.N * (P.H / G::TR) * (P.W / (2 * TPW)) * (P.Co / BN));
+    const char *name = "conv_wino";
+    if (prof_enabled()) name = prof_label("conv_wino3<%dx%d,nt%d>|M=%d,N=%d,K=%d", G::TR, 2 * TPW, NT, P.M, P.Co, P.K);
+    ProfScope prof(name, P.flops, P.bytes, s, true);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(G::NTHR), G::LDS_BYTES, s, P);
+    return check_launch("wino3_kernel");
+}
+
+static int tune(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+}  // namespace wino
+
+// Shapes the Winograd kernel takes: 3x3, stride 1, pad 1, output the size of the input, whole 128-channel output tiles,
+// 8-channel input blocks, rows of whole 64-pixel segments, tensors below 1 GiB (32-bit offsets with an additive
+// out-of-range penalty).
+bool wino3_ok(const ConvGemmParams &P) {
+    static const int on = wino::tune("VQ2_WINO", 1);
+    const long gib = 1L << 30;
+    return on && P.KH == 3 && P.KW == 3 && P.stride == 1 && P.pad_h == 1 && P.pad_w == 1 && P.phases == 1 &&
+           P.Ho == P.H && P.Wo == P.W && P.Hy == P.H && P.Wy == P.W && P.Ci % wino::BK == 0 && P.Ci >= 64 &&
+           P.Co % wino::BN == 0 && P.W % 64 == 0 && P.H % 2 == 0 && P.ldx % 4 == 0 &&
+           (long)P.N * P.H * P.W * P.ldx * 4 < gib && (long)P.N * P.H * P.W * P.ldy * 4 < gib &&
+           (long)P.N * P.H * P.W * (P.ldm > P.ldr ? P.ldm : P.ldr) * 4 < gib && (long)P.Co * P.K * 4 < gib;
+}
+
+// (NT = 1 -- eight waves of 32 pairs x 32 channels, four per SIMD at <= 128 registers -- measured no faster than NT = 2
+//  and does not fit its register budget once the staging loads are held across the MFMA phase; not instantiated.)
+int launch_wino3(const ConvGemmParams &P, hipStream_t s) { return wino::launch<32, 2>(P, s); }
+
+}  // namespace vq2
