@@ -121,7 +121,7 @@ def _launched(amd, fn):
     return out, [ln.split()[0] for ln in buf.value.decode().splitlines()]
 
 
-@pytest.mark.parametrize("shape", [(2, 6, 64, 64, 128), (1, 4, 128, 72, 256), (3, 2, 64, 128, 128)])
+@pytest.mark.parametrize("shape", [(2, 6, 64, 64, 128), (1, 4, 128, 72, 256), (3, 2, 64, 128, 128), (2, 6, 128, 128, 256)])
 def test_winograd_rows_conv_forward_and_data_gradient(amd, shape):
     """3x3 stride-1 convolutions with >= 64 input channels, whole 128-channel output tiles and rows of whole 64-pixel
     segments run as F(2,3) Winograd along the rows (csrc/vq2_wino.hip): forward with ReLU-in / bias / residual / ReLU-out
@@ -162,6 +162,18 @@ def test_winograd_rows_conv_forward_and_data_gradient(amd, shape):
         F.conv2d(F.relu(xr), wt.cpu().double(), None, padding=1).backward(dy.permute(0, 3, 1, 2).cpu().double())
         refg = xr.grad.permute(0, 2, 3, 1) + wide_in[..., 0:ci].cpu().double()
         close(dx.double(), refg, rtol=0, atol=5e-6 * float(refg.abs().max()), what=tag + ".dx")
+        # weight and bias gradient: the same transform on the reduction side (wgrad_fast_kernel<..., WINO>, whole 128-channel
+        # tiles on both sides), with and without the fused ReLU on x, through channel slices
+        if co % 128 == 0:
+            wr = wt.cpu().double().clone().requires_grad_(True)
+            br = b.cpu().double().clone().requires_grad_(True)
+            for relu_in in (True, False):
+                (dw, db), seen = _launched(amd, lambda: ops.conv_wgrad(spec, x, dy, relu_in, wt, b))
+                assert any("wino" in k and k.startswith("wgrad") for k in seen), seen
+                wr.grad = br.grad = None
+                F.conv2d(F.relu(x64) if relu_in else x64, wr, br, padding=1).backward(dy.permute(0, 3, 1, 2).cpu().double())
+                close(dw.double(), wr.grad, rtol=0, atol=1e-5 * float(wr.grad.abs().max()), what=tag + ".dw%d" % relu_in)
+                close(db.double(), br.grad, rtol=0, atol=1e-5 * float(br.grad.abs().max()), what=tag + ".db%d" % relu_in)
 
 
 def test_layout_conversion_generic_channels(amd):

@@ -247,7 +247,15 @@ __device__ __forceinline__ float4 as_f4w(u32x4w v) {
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-template <int WAVES_M, int WAVES_N, int MT, int NT, bool RELU_X, bool RELU_G>
+// WINO (3x3 stride-1 pad-1, 128 x 128 tiles, I % 128 == 0, Wo % 64 == 0): the same sum as F(2,3) Winograd along the image
+// rows (csrc/vq2_wino.hip has the forward form).  The reduction runs over column PAIRS (P.M, P.rows_per_split, P.Wo are
+// in pairs... P.Wo stays in pixels), the K axis is (kernel row kh, Winograd index v, channel): for pair t of a row with
+// input columns d0..d3 = 2t-1 .. 2t+2 and gradients g0, g1 of its two pixels
+//     S_v[kh] += E_v^T V_v,   E = (g0, g0 + g1, g0 - g1, g1),   V = (d0 - d2, d1 + d2, d2 - d1, d3 - d1)
+// and the reduction kernels finish with  dw[kh][0] = S0 + (S1 + S2)/2, dw[kh][1] = (S1 - S2)/2, dw[kh][2] = (S1 + S2)/2 + S3:
+// 12 products per pair instead of 18 -- 2/3 of the matrix instructions.  A workgroup owns ONE (kh, v, 128-channel block):
+// v is workgroup-uniform, so the transform is one fused multiply-add by +-1 per staged element (exact).
+template <int WAVES_M, int WAVES_N, int MT, int NT, bool RELU_X, bool RELU_G, bool WINO = false>
 __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
     constexpr int BMO = WAVES_M * MT * 32;
     constexpr int BNK = WAVES_N * NT * 32;
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
     const int m_end = min(P.M, m_begin + P.rows_per_split);
 
     const __amdgpu_buffer_rsrc_t rg =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.g), 0, P.M * P.ldg * 4, WRSRC_FLAGS);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.g), 0, (WINO ? 2 : 1) * P.M * P.ldg * 4, WRSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rx =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x), 0, P.N * P.H * P.W * P.ldx * 4, WRSRC_FLAGS);
 
@@ -290,27 +298,79 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
         kh = tap / P.KW;
         kw = tap - kh * P.KW;
     }
+    // WINO: the K tile is one (kh, v) of all threads (I % BNK == 0); column offsets of the two input pixels of V_v and of
+    // the gradient pixel(s) of E_v, relative to the pair's first pixel
+    int nu = 0, xo_a = 0, xo_b = 0, go_a = 0;
+    bool g_two = false;
+    float sv = -1.f, sg = 1.f;
+    if constexpr (WINO) {
+        const int vt = k0 / P.I;
+        kh = vt >> 2; nu = vt & 3; kw = 0;
+        ci = x_k - vt * P.I;
+        xo_a = (nu == 0) ? -1 : (nu == 1) ? 0 : (nu == 2) ? 1 : 2;     // V = x[a] + sv * x[b]
+        xo_b = (nu == 0) ? 1 : (nu == 1) ? 1 : 0;
+        sv = (nu == 1) ? 1.f : -1.f;
+        go_a = (nu == 3) ? 1 : 0;                                       // E = g[a] (+ sg * g[1])
+        g_two = (nu == 1 || nu == 2);
+        sg = (nu == 2) ? -1.f : 1.f;
+    }
     int g_const[G_LD], x_const[X_LD], x_iw[X_LD];
 #pragma unroll
-    for (int j = 0; j < G_LD; ++j) g_const[j] = ((g_r + j * G_RSTEP) * P.ldg + g_c) * 4;
+    for (int j = 0; j < G_LD; ++j) g_const[j] = ((g_r + j * G_RSTEP) * (WINO ? 2 : 1) * P.ldg + g_c) * 4;
 #pragma unroll
     for (int j = 0; j < X_LD; ++j) {
         const int rj = x_r + j * X_RSTEP;                    // row inside the 32-row chunk
+        if constexpr (WINO) {
+            x_iw[j] = 2 * rj;                                // + 2 * pair0 + xo = input column
+            x_const[j] = ((kh * P.W + 2 * rj) * P.ldx + ci) * 4;
+        } else {
         x_iw[j] = rj * P.stride - P.pad + kw;                // + wo0*stride = input column
         x_const[j] = ((kh * P.W + kw + rj * P.stride) * P.ldx + ci) * 4;
+        }
     }
     // wave-uniform chunk position (scalar registers)
     int un, uho, uwo;
+    const int row_len = WINO ? P.Wo / 2 : P.Wo;              // reduction positions per image row (WINO: column pairs)
     {
-        const int HoWo = P.Ho * P.Wo;
+        const int HoWo = P.Ho * row_len;
         un = m_begin / HoWo;
         const int r = m_begin - un * HoWo;
-        uho = r / P.Wo;
-        uwo = r - uho * P.Wo;
+        uho = r / row_len;
+        uwo = r - uho * row_len;
     }
 
     u32x4w rgv[G_LD], rxv[X_LD];
+    u32x4w rgw[WINO ? G_LD : 1], rxw[WINO ? X_LD : 1];       // WINO: the second pixel of every staged element
+    auto load_chunk_wino = [&](int mbase) {
+        const int rows_left = m_end - mbase;                  // uniform (pairs)
+        const int gbase = ((un * P.Ho + uho) * P.Wo + 2 * uwo + go_a) * P.ldg * 4;   // uniform
+#pragma unroll
+        for (int j = 0; j < G_LD; ++j) {
+            const bool v = g_cv && (g_r + j * G_RSTEP) < rows_left;
+            rgv[j] = __builtin_amdgcn_raw_buffer_load_b128(rg, v ? gbase + g_const[j] : WOOB, 0, 0);
+            rgw[j] = __builtin_amdgcn_raw_buffer_load_b128(rg, (v && g_two) ? gbase + g_const[j] + P.ldg * 4 : WOOB, 0, 0);
+        }
+        const int ihu = uho - 1;                               // pad 1
+        const int xbase = ((un * P.H + ihu) * P.W + 2 * uwo) * P.ldx * 4;             // uniform
+        const bool hv = x_kv && (unsigned)(ihu + kh) < (unsigned)P.H;
+        const int iwu = 2 * uwo;
+        const int xa = xo_a * P.ldx * 4, xb = xo_b * P.ldx * 4;
+#pragma unroll
+        for (int j = 0; j < X_LD; ++j) {
+            const bool v = hv && (x_r + j * X_RSTEP) < rows_left;
+            const bool va = v && (unsigned)(iwu + x_iw[j] + xo_a) < (unsigned)P.W;
+            const bool vb = v && (unsigned)(iwu + x_iw[j] + xo_b) < (unsigned)P.W;
+            rxv[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, va ? xbase + x_const[j] + xa : WOOB, 0, 0);
+            rxw[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, vb ? xbase + x_const[j] + xb : WOOB, 0, 0);
+        }
+        uwo += WG_BKR;
+        if (uwo >= row_len) {
+            uwo = 0;
+            if (++uho == P.Ho) { uho = 0; ++un; }
+        }
+    };
     auto load_chunk = [&](int mbase) {
+        if constexpr (WINO) { load_chunk_wino(mbase); return; }
         const int rows_left = m_end - mbase;                  // uniform
         const int gbase = mbase * P.ldg * 4;                  // uniform
 #pragma unroll
@@ -339,14 +399,27 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
         float *xs = Xs + buf * WG_BKR * BNK;
 #pragma unroll
         for (int j = 0; j < G_LD; ++j) {
-            const float4 v = as_f4w(rgv[j]);
+            float4 v = as_f4w(rgv[j]);
+            if constexpr (WINO) {
+                if (g_two) {                                   // workgroup-uniform
+                    const float4 w = as_f4w(rgw[j]);
+                    v = make_float4(fmaf(sg, w.x, v.x), fmaf(sg, w.y, v.y), fmaf(sg, w.z, v.z), fmaf(sg, w.w, v.w));
+                }
+            }
             *reinterpret_cast<float4 *>(gs + (g_r + j * G_RSTEP) * BMO + (tid % G_C4) * 4) = RELU_G ? relu4(v) : v;
         }
 #pragma unroll
         for (int j = 0; j < X_LD; ++j) {
-            const float4 v = as_f4w(rxv[j]);
+            float4 v = as_f4w(rxv[j]);
+            if constexpr (WINO) {
+                float4 w = as_f4w(rxw[j]);
+                if (RELU_X) { v = relu4(v); w = relu4(w); }
+                v = make_float4(fmaf(sv, w.x, v.x), fmaf(sv, w.y, v.y), fmaf(sv, w.z, v.z), fmaf(sv, w.w, v.w));
+                *reinterpret_cast<float4 *>(xs + (x_r + j * X_RSTEP) * BNK + (tid % X_C4) * 4) = v;
+            } else {
             if (X_C4 * X_RSTEP == 256 || x_act)
                 *reinterpret_cast<float4 *>(xs + (x_r + j * X_RSTEP) * BNK + (tid % X_C4) * 4) = RELU_X ? relu4(v) : v;
+            }
         }
     };
 
@@ -365,7 +438,8 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
     }
     __syncthreads();
     const int fr = lane & 31, fk = lane >> 5;
-    const bool do_bias = P.bias_ws != nullptr && !P.bias_taps && k0 == 0 && tid < BMO;
+    // (WINO: the tile (kh 0, v 1) stages E = g0 + g1 -- its column sums over the pairs are the sums over the pixels)
+    const bool do_bias = P.bias_ws != nullptr && !P.bias_taps && k0 == (WINO ? P.I : 0) && tid < BMO;
     // exchanged roles: dy is the gathered operand; its centre tap visits every pixel exactly once, so the
     // column sums of that k-block of the staged X tile are the bias gradient (tile width == one tap)
     int bx_col = -1;   // this thread's slot in a bias_ws row when its k column belongs to a bias tap
@@ -455,9 +529,48 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
                                                            const float *__restrict__ bias_ws, float *__restrict__ db,
                                                            int swapped, int bias_splits) {
     __shared__ float part[8][33];
-    const int K = taps * I;
-    const int total = O * K;
     const int lane = threadIdx.x & 31, g = threadIdx.x >> 5;
+    if (swapped & 2) {   // Winograd slabs [S][O][(kh, v, i)] -> dw[o][i][kh][0..2]; one thread column per (o, kh, i)
+        __shared__ float part4[4][8][33];
+        const int KW_ = 12 * I, stride = O * KW_, cols = O * 3 * I;
+        for (int base = blockIdx.x * 32; base < cols; base += gridDim.x * 32) {
+            const int t = base + lane;
+            float s[4] = {0.f, 0.f, 0.f, 0.f};
+            int o = 0, kh = 0, i = 0;
+            if (t < cols) {
+                o = t / (3 * I);
+                const int r = t - o * 3 * I;
+                kh = r / I; i = r - kh * I;
+                const float *src = ws + (size_t)o * KW_ + (kh * 4) * I + i;
+                for (int z = g; z < S; z += 8) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) s[v] += src[(size_t)z * stride + v * I];
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) part4[v][g][lane] = s[v];
+            __syncthreads();
+            if (g == 0 && t < cols && o < Or && i < Ir) {
+                float r4[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    float a = part4[v][0][lane];
+#pragma unroll
+                    for (int q = 1; q < 8; ++q) a += part4[v][q][lane];
+                    r4[v] = a;
+                }
+                float *dst = dw + ((size_t)o * Ir + i) * 9 + kh * 3;
+                const float h = 0.5f * (r4[1] + r4[2]);
+                dst[0] = r4[0] + h;
+                dst[1] = 0.5f * (r4[1] - r4[2]);
+                dst[2] = h + r4[3];
+            }
+            __syncthreads();
+        }
+    }
+    const int K = taps * I;
+    const int total = (swapped & 2) ? 0 : O * K;
+    swapped &= 1;
     for (int base = blockIdx.x * 32; base < total; base += gridDim.x * 32) {
         const int t = base + lane;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -515,6 +628,7 @@ static int colsum_impl(const float *dy, int64_t rows, int C, int ld, float *db, 
 __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const vq2_wgrad_job *__restrict__ jobs, int njobs,
                                                                    int64_t total_units) {
     __shared__ float part[8][33];
+    __shared__ float part4[4][8][33];
     const int lane = threadIdx.x & 31, g = threadIdx.x >> 5;
     for (int64_t u = blockIdx.x; u < total_units; u += gridDim.x) {
         int lo = 0, hi = njobs - 1;
@@ -525,6 +639,42 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const vq2_wgr
         const vq2_wgrad_job j = jobs[lo];
         const int lu = (int)(u - j.unit_offset);
         const bool is_bias = lu >= j.n_units_w;
+        if ((j.swapped & 2) && !is_bias) {   // Winograd slabs (see wgrad_reduce_kernel): unit = 32 columns (o, kh, i)
+            const int KW_ = 12 * j.I, stride = j.O * KW_, cols = j.O * 3 * j.I;
+            const int t = lu * 32 + lane;
+            float s[4] = {0.f, 0.f, 0.f, 0.f};
+            int o = 0, kh = 0, i = 0;
+            if (t < cols) {
+                o = t / (3 * j.I);
+                const int r = t - o * 3 * j.I;
+                kh = r / j.I; i = r - kh * j.I;
+                const float *src = j.ws + (size_t)o * KW_ + (kh * 4) * j.I + i;
+                for (int z = g; z < j.S; z += 8) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) s[v] += src[(size_t)z * stride + v * j.I];
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) part4[v][g][lane] = s[v];
+            __syncthreads();
+            if (g == 0 && t < cols && o < j.Or && i < j.Ir) {
+                float r4[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    float a = part4[v][0][lane];
+#pragma unroll
+                    for (int q = 1; q < 8; ++q) a += part4[v][q][lane];
+                    r4[v] = a;
+                }
+                float *dst = j.dw + ((size_t)o * j.Ir + i) * 9 + kh * 3;
+                const float h = 0.5f * (r4[1] + r4[2]);
+                dst[0] = r4[0] + h;
+                dst[1] = 0.5f * (r4[1] - r4[2]);
+                dst[2] = h + r4[3];
+            }
+            __syncthreads();
+            continue;
+        }
         const int K = j.taps * j.I;
         const int total = is_bias ? (j.bias_splits ? j.I : j.O) : j.O * K;      // stride between splits
         const int limit = is_bias ? (j.bias_splits ? j.Ir : j.Or) : j.O * K;
@@ -554,7 +704,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const vq2_wgr
                 const int o = t / K, k = t - o * K;
                 const int tap = k / j.I, i = k - tap * j.I;
                 if (o < j.Or && i < j.Ir) {
-                    if (j.swapped) j.dw[((size_t)i * j.Or + o) * j.taps + (j.taps - 1 - tap)] = s;
+                    if (j.swapped & 1) j.dw[((size_t)i * j.Or + o) * j.taps + (j.taps - 1 - tap)] = s;
                     else j.dw[((size_t)o * j.Ir + i) * j.taps + tap] = s;
                 }
             }
@@ -566,6 +716,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const vq2_wgr
 struct WgradPlan {
     int O, I, K, M, S, rows_per_split, bmo, bnk;
     int swapped;  // roles of x and dy exchanged (see plan_wgrad)
+    int wino;     // F(2,3) Winograd along the rows: K = 12 * I (kh, v, i), M in column pairs (wgrad_fast_kernel<..., WINO>)
 };
 
 static WgradPlan plan_wgrad(const vq2_conv_desc *d) {
@@ -589,13 +740,23 @@ static WgradPlan plan_wgrad(const vq2_conv_desc *d) {
         p.M = d->N * d->H * d->W;
     }
     p.K = d->KH * d->KW * p.I;
+    p.wino = 0;
+    static const int wwino = getenv("VQ2_WWINO") ? atoi(getenv("VQ2_WWINO")) : 1;
+    static const int wfast = getenv("VQ2_WFAST") ? atoi(getenv("VQ2_WFAST")) : 1;
+    if (wwino && wfast && !p.swapped && !d->transposed && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 &&
+        p.O % 128 == 0 && p.I % 128 == 0 && d->W % 64 == 0 && (long)d->N * d->H * d->W * d->ldx < (1L << 29) &&
+        (long)d->N * d->H * d->W * d->ldy < (1L << 29)) {
+        p.wino = 1;
+        p.K = 12 * p.I;
+        p.M = p.M / 2;
+    }
     // output tile (o x k): the candidate that wastes the least padded work, larger tile on ties
     // 128 x 96 = one kernel row of a 3x3 conv with 32 gathered channels (the ResBlock weight gradient with
     // exchanged roles, K = 288): 48 MFMAs per wave and chunk instead of 16 for the same staging
     static const int cand[6][2] = {{128, 128}, {64, 128}, {32, 256}, {128, 96}, {128, 32}, {64, 64}};
     static const int t96 = getenv("VQ2_W96") ? atoi(getenv("VQ2_W96")) : 1;
     long best = -1;
-    for (int c = 0; c < 6; ++c) {
+    for (int c = 0; c < (p.wino ? 1 : 6); ++c) {
         if (cand[c][1] == 96 && (!t96 || p.M < 65536)) continue;   // measured: +6 % at 131072 rows, -9 % at 32768
         const long po = (p.O + cand[c][0] - 1) / cand[c][0] * cand[c][0];
         const long pk = (p.K + cand[c][1] - 1) / cand[c][1] * cand[c][1];
@@ -780,12 +941,18 @@ static int wgrad_impl(const vq2_conv_desc *d, int flags, const float *x, const f
     int e;
     const double cir_ = d->Cir ? d->Cir : d->Ci, cor_ = d->Cor ? d->Cor : d->Co;
     const double pix_in_ = (double)d->N * d->H * d->W;
-    const double pix_out_ = d->transposed ? 4.0 * pix_in_ : (double)P.M;
+    const double pix_out_ = d->transposed ? 4.0 * pix_in_ : (double)P.M * (p.wino ? 2.0 : 1.0);
     const double macs_ = d->transposed ? pix_in_ * 16.0 * cir_ * cor_ : pix_out_ * d->KH * d->KW * cir_ * cor_;
     const char *pname = "wgrad";
-    if (prof_enabled()) pname = prof_label("wgrad<%dx%d>%s|O=%d,K=%d,M=%d,S=%d,k%d", p.bmo, p.bnk, p.swapped ? "sw" : "", p.O, p.K, p.M, p.S, d->KH);
+    if (prof_enabled()) pname = prof_label("wgrad<%dx%d>%s|O=%d,K=%d,M=%d,S=%d,k%d", p.bmo, p.bnk, p.swapped ? "sw" : (p.wino ? "wino" : ""), p.O, p.K, p.M, p.S, d->KH);
     ProfScope prof(pname, 2.0 * macs_, 4.0 * (pix_in_ * cir_ + pix_out_ * cor_ + cir_ * cor_ * d->KH * d->KW), s);
-    if (p.bmo == 128 && p.bnk == 128) e = launch_wgrad<2, 2, 2, 2>(P, p.S, s);
+    if (p.wino) {
+        auto kern = P.relu_x ? wgrad_fast_kernel<2, 2, 2, 2, true, false, true> : wgrad_fast_kernel<2, 2, 2, 2, false, false, true>;
+        const size_t lds = (size_t)2 * WG_BKR * 256 * sizeof(float);
+        allow_big_lds(kern, lds);
+        hipLaunchKernelGGL(kern, dim3((P.K / 128) * ((P.O + 127) / 128) * p.S), dim3(256), lds, s, P);
+        e = check_launch("wgrad_fast_kernel<wino>");
+    } else if (p.bmo == 128 && p.bnk == 128) e = launch_wgrad<2, 2, 2, 2>(P, p.S, s);
     else if (p.bmo == 64 && p.bnk == 128) e = launch_wgrad<1, 4, 2, 1>(P, p.S, s);
     else if (p.bmo == 32) e = launch_wgrad<1, 4, 1, 2>(P, p.S, s);      // 32 x 256
     else if (p.bmo == 128 && p.bnk == 96) e = launch_wgrad<4, 1, 1, 3>(P, p.S, s);
@@ -799,7 +966,7 @@ static int wgrad_impl(const vq2_conv_desc *d, int flags, const float *x, const f
     const bool sw = d->transposed || p.swapped;
     const int Or = sw ? cir : cor, Ir = sw ? cor : cir;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, P.ws, dw, p.O, p.I, Or, Ir, d->KH * d->KW,
-                       p.S, P.bias_ws, db, p.swapped, P.bias_taps ? p.S * P.bias_nslots : 0);
+                       p.S, P.bias_ws, db, p.swapped | (p.wino << 1), P.bias_taps ? p.S * P.bias_nslots : 0);
     return check_launch("wgrad_reduce_kernel");
 }
 
@@ -821,9 +988,9 @@ extern "C" int vq2_wgrad_job_init(const vq2_conv_desc *d, const void *ws, float 
     job->ws = w; job->dw = dw; job->db = nullptr; job->bias_ws = nullptr;
     const bool sw = d->transposed || p.swapped;
     job->O = p.O; job->I = p.I; job->Or = sw ? cir : cor; job->Ir = sw ? cor : cir;
-    job->swapped = p.swapped; job->bias_splits = 0;
+    job->swapped = p.swapped | (p.wino << 1); job->bias_splits = 0;
     job->taps = d->KH * d->KW; job->S = p.S;
-    job->n_units_w = (p.O * p.K + 31) / 32;
+    job->n_units_w = p.wino ? (p.O * 3 * p.I + 31) / 32 : (p.O * p.K + 31) / 32;
     job->n_units_b = 0;
     if (db) {
         int taps, nslots;
