@@ -176,6 +176,41 @@ def test_winograd_rows_conv_forward_and_data_gradient(amd, shape):
                 close(db.double(), br.grad, rtol=0, atol=1e-5 * float(br.grad.abs().max()), what=tag + ".db%d" % relu_in)
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 128, 64, 128), (1, 4, 256, 40, 256), (3, 12, 128, 32, 128)])
+def test_winograd_by_parity_k4s2_conv_forward_and_convT_data_gradient(amd, shape):
+    """4x4 stride-2 convolutions with whole 128-channel output tiles and output rows of whole 64-pixel segments run as
+    two F(2,2) filters by column parity (csrc/vq2_wino.hip): the forward with ReLU-in / bias / ReLU-out through channel
+    slices, and the data gradient of ConvTranspose2d(k4,s2,p1) (the same operation on dy) with its ReLU mask, vs fp64."""
+    from vqvae2_amd import ops
+    dev = torch.device("cuda:0")
+    n, h, w, ci, co = shape                                   # input h x w, output h/2 x w/2
+    tag = "k4s2_%dx%dx%d" % (h, w, ci)
+    wide_in = t(rng.normal(11, tag + ".in", (n, h, w, ci + 4))).to(dev)
+    x = wide_in[..., 4:4 + ci]
+    wide_out = torch.full((n, h // 2, w // 2, co + 8), 7.0, device=dev)
+    wt = t(rng.uniform(11, tag + ".w", (co, ci, 4, 4), -0.1, 0.1)).to(dev)
+    b = t(rng.uniform(11, tag + ".b", (co,), -1, 1)).to(dev)
+    spec = ops.ConvSpec(False, ci, co, 4, 2, 1)
+    y, seen = _launched(amd, lambda: ops.conv_forward(spec, x, wt, b, ops.VQ2_RELU_IN | ops.VQ2_RELU_OUT,
+                                                      out=wide_out[..., 4:4 + co]))
+    assert any(k.startswith("conv_wino_k4s2") for k in seen), seen
+    x64 = x.permute(0, 3, 1, 2).cpu().double()
+    ref = F.relu(F.conv2d(F.relu(x64), wt.cpu().double(), b.cpu().double(), stride=2, padding=1)).permute(0, 2, 3, 1)
+    close(y.double(), ref, rtol=0, atol=5e-6 * float(ref.abs().max()), what=tag + ".y")
+    assert float(wide_out[..., :4].min()) == 7.0 and float(wide_out[..., 4 + co:].max()) == 7.0
+    # ConvTranspose2d(co -> ci) backward: dx[n, h/2, w/2, co] = strided conv of dy[n, h, w, ci] with the same taps
+    tspec = ops.ConvSpec(True, co, ci, 4, 2, 1)
+    wtt = t(rng.uniform(11, tag + ".wt", (co, ci, 4, 4), -0.1, 0.1)).to(dev)     # IOHW of the transposed conv
+    xin = t(rng.normal(11, tag + ".xin", (n, h // 2, w // 2, co))).to(dev)
+    dy = t(rng.normal(11, tag + ".dy", (n, h, w, ci))).to(dev)
+    dx, seen = _launched(amd, lambda: ops.conv_dgrad(tspec, (n, h // 2, w // 2, co), dy, wtt, mask=xin))
+    assert any(k.startswith("conv_wino_k4s2") for k in seen), seen
+    xr = xin.permute(0, 3, 1, 2).cpu().double().clone().requires_grad_(True)
+    F.conv_transpose2d(F.relu(xr), wtt.cpu().double(), None, stride=2, padding=1).backward(dy.permute(0, 3, 1, 2).cpu().double())
+    refg = xr.grad.permute(0, 2, 3, 1)
+    close(dx.double(), refg, rtol=0, atol=5e-6 * float(refg.abs().max()), what=tag + ".dx")
+
+
 def test_layout_conversion_generic_channels(amd):
     from vqvae2_amd import ops
     dev = torch.device("cuda:0")

@@ -45,6 +45,64 @@ struct Geo {
 __device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
+// Epilogue shared by the kernels of this file: lane (lane & 31) of a wave holds the first output pixel of its pair in
+// pix_lane (shared through ds_bpermute); vals(j, r, y0, y1) yields the two outputs of accumulator row r of column block j.
+// Then exactly the direct kernel's epilogue (vq2_conv.hip): bias, ReLU mask, residual, ReLU, strided store.
+template <int NT, class F>
+__device__ __forceinline__ void store_pairs(const ConvGemmParams &P, int co0, int lane, int pix_lane, F vals) {
+    const int ybytes = P.N * P.Hy * P.Wy * 4;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(P.y, 0, ybytes * P.ldy, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rmk =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.mask ? P.mask : P.y), 0, P.mask ? ybytes * P.ldm : 0, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.res ? P.res : P.y), 0, P.res ? ybytes * P.ldr : 0, RSRC_FLAGS);
+    const bool has_mask = P.mask != nullptr, has_res = P.res != nullptr;
+    const bool mask_first = has_mask && !P.mask_after, mask_last = has_mask && P.mask_after;
+    const int colq = lane & 31, rowq = 4 * (lane >> 5);
+    const int ldy4 = P.ldy * 4, ldm4 = P.ldm * 4, ldr4 = P.ldr * 4;
+    const int relu_bits = P.relu_out ? 0 : (int)0x80000000;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int co = co0 + j * 32 + colq;
+        const float bv = (P.bias && co < P.nbias) ? P.bias[co] : 0.f;
+        const int co4 = co * 4;
+#pragma unroll
+        for (int rb4 = 0; rb4 < 16; rb4 += 4) {
+            int pix[8];
+            float mk[8], rs[8], val[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = rb4 + q;
+                const int rr = rowq + (r & 3) + 8 * (r >> 2);
+                const int p0 = __shfl(pix_lane, rr, 64);
+                pix[2 * q] = p0;
+                pix[2 * q + 1] = p0 + 1;
+                vals(j, r, val[2 * q], val[2 * q + 1]);
+            }
+            if (has_mask) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    mk[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rmk, pix[q] * ldm4 + co4, 0, 0));
+            }
+            if (has_res) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    rs[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, pix[q] * ldr4 + co4, 0, 0));
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float v = val[q] + bv;
+                if (mask_first) v = (mk[q] > 0.f) ? v : 0.f;
+                if (has_res) v += rs[q];
+                if (mask_last) v = (mk[q] > 0.f) ? v : 0.f;
+                v = relu_floor(v, relu_bits);
+                if (VQ2_WINO_EXP != 6 || v == 123.456f)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, pix[q] * ldy4 + co4, 0, 0);
+            }
+        }
+    }
+}
+
 template <int TPW, int NT, bool RELU_IN>
 __global__ __launch_bounds__(128 * (4 / NT), NT == 1 ? 4 : 2) void wino3_kernel(const ConvGemmParams P) {
     using G = Geo<TPW, NT>;
@@ -193,61 +251,196 @@ __global__ __launch_bounds__(128 * (4 / NT), NT == 1 ? 4 : 2) void wino3_kernel(
     }
 
     // ---- epilogue: output transform in registers, then the direct kernel's epilogue on two pixels per row
-    const int ybytes = P.N * P.Hy * P.Wy * 4;
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(P.y, 0, ybytes * P.ldy, RSRC_FLAGS);
-    const __amdgpu_buffer_rsrc_t rmk =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.mask ? P.mask : P.y), 0, P.mask ? ybytes * P.ldm : 0, RSRC_FLAGS);
-    const __amdgpu_buffer_rsrc_t rrs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.res ? P.res : P.y), 0, P.res ? ybytes * P.ldr : 0, RSRC_FLAGS);
-    const bool has_mask = P.mask != nullptr, has_res = P.res != nullptr;
-    const bool mask_first = has_mask && !P.mask_after, mask_last = has_mask && P.mask_after;
-    const int colq = lane & 31, rowq = 4 * (lane >> 5);
-    const int ldy4 = P.ldy * 4, ldm4 = P.ldm * 4, ldr4 = P.ldr * 4;
-    const int relu_bits = P.relu_out ? 0 : (int)0x80000000;
-    // pixel of pair (wm * 32 + lane & 31), shared through ds_bpermute
-    const int pix_lane = ((n * P.H + h0 + pr_l) * P.W + w0 + 2 * pt_l);
+    const int pix_lane = ((n * P.H + h0 + pr_l) * P.W + w0 + 2 * pt_l);   // first pixel of pair (wm * 32 + lane & 31)
+    store_pairs<NT>(P, n0 + wn * NT * 32, lane, pix_lane, [&](int j, int r, float &y0, float &y1) {
+        const float m0 = acc[0][j][r], m1 = acc[1][j][r], m2 = acc[2][j][r], m3 = acc[3][j][r];
+        y0 = m0 + 0.5f * (m1 + m2);
+        y1 = 0.5f * (m1 - m2) - m3;
+    });
+}
+
+// ====================================================================== 4x4 stride-2 pad-1 convolution
+// (the down-sampling convs, vqvae.py:105-107, and the data gradient of ConvTranspose2d(k4,s2,p1), which is the same
+// operation on dy.)  Along a row the four taps split by column parity into two 2-tap stride-1 filters,
+//     y[wo] = (g0 o[wo] + g2 o[wo+1]) + (g1 e[wo] + g3 e[wo+1]),   o[i] = x[2i-1], e[i] = x[2i],
+// and each of them runs as F(2,2): for the output pair (2t, 2t+1) and d0..d2 = three consecutive entries of o (or e)
+//     M1 = (d0 - d1) ga,  M2 = d1 (ga + gb),  M3 = (d1 - d2) gb,   y[2t] = M1 + M2,  y[2t+1] = M2 - M3
+// -- three products instead of four: 3/4 of the matrix instructions of the direct form, three accumulator sets
+// (summed over kernel rows, parities and channels before the output transform).  Same tile and pipeline as above; the
+// patch of one (kernel row, 8-channel block) holds both parities de-interleaved ([row][parity][65]: a lane's three
+// reads are then 96 bytes from its neighbour's, conflict-free) and serves two chunks.
+namespace k4 {
+constexpr int NPH = 65;                      // entries of one parity in a patch row: 2t + {0,1,2}, t < 32
+constexpr int NPX = 2 * 2 * NPH;             // [output row of the tile][parity][entry]
+constexpr int A_FLOATS = (NPX + 1) * LDK;
+constexpr int A_ITEMS = NPX * 2;
+constexpr int A_LD = (A_ITEMS + 255) / 256;
+constexpr int B3_FLOATS = 3 * BN * LDK;
+constexpr size_t LDS_BYTES = (size_t)2 * (A_FLOATS + B3_FLOATS) * sizeof(float);
+}  // namespace k4
+
+template <bool RELU_IN>
+__global__ __launch_bounds__(256, 2) void wino_k4s2_kernel(const ConvGemmParams P) {
+    constexpr int NT = 2, NWN = 2;
+    using namespace k4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                    // [2][A_FLOATS]
+    float *Bs = smem + 2 * A_FLOATS;     // [2][3][BN][LDK]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int ntn = P.Co / BN, tw = P.Wo / 64, th = P.Ho / 2;
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = (vid % ntn) * BN;
+    const int sp = vid / ntn;
+    const int wb = sp % tw, hb = (sp / tw) % th, n = sp / (tw * th);
+    const int h0 = hb * 2, w0 = wb * 64;      // first output row / column of the tile
+    const int cx0 = 2 * w0 - 1;               // input column of entry 0 of the odd parity
+
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x), 0, P.N * P.H * P.W * P.ldx * 4, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.w), 0, P.Co * P.K * 4, RSRC_FLAGS);
+
+    // patch items (entry, quad) for kernel row 0; kernel row kh adds kh input rows.  a_vh: bit kh = that row is inside
+    int a_off[A_LD], a_dst[A_LD];
+    unsigned a_vh[A_LD];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int co = n0 + (wn * NT + j) * 32 + colq;
-        const float bv = (P.bias && co < P.nbias) ? P.bias[co] : 0.f;
-        const int co4 = co * 4;
+    for (int j = 0; j < A_LD; ++j) {
+        const int it = tid + 256 * j;
+        const bool ok = it < A_ITEMS;
+        const int px = ok ? (it >> 1) : 0, q = it & 1;
+        const int r = px / (2 * NPH), rem = px - r * 2 * NPH;
+        const int par = rem / NPH, i = rem - par * NPH;
+        const int col = cx0 + 2 * i + par;
+        const int row0 = 2 * (h0 + r) - 1;
+        const bool cin = ok && (unsigned)col < (unsigned)P.W;
+        a_off[j] = (((n * P.H + row0) * P.W + col) * P.ldx + 4 * q) * 4;
+        a_vh[j] = 0;
+        for (int kh = 0; kh < 4; ++kh) a_vh[j] |= (cin && (unsigned)(row0 + kh) < (unsigned)P.H ? 1u : 0u) << kh;
+        a_dst[j] = (ok ? px : NPX) * LDK + 4 * q;
+    }
+    const int bco = tid >> 1, bq = tid & 1;
+    const int b_off = ((n0 + bco) * P.K + 4 * bq) * 4;
+    const int b_dst = bco * LDK + 4 * bq;
+    const int ci4 = P.Ci * 4, row4 = P.W * P.ldx * 4;
+
+    u32x4 ra[A_LD], rb[2];
+    auto load_b = [&](int kh, int par, int cb) {
+        const int kb = ((kh * 4 + par) * P.Ci + cb) * 4;   // scalar: tap (kh, par); the second tap is (kh, par + 2)
+        rb[0] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_off + kb, 0, 0);
+        rb[1] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_off + kb + 2 * ci4, 0, 0);
+    };
+    auto store_b = [&](float *b) {
+        const float4 ga = as_f4(rb[0]), gb = as_f4(rb[1]);
+        *reinterpret_cast<float4 *>(b + 0 * BN * LDK + b_dst) = ga;
+        *reinterpret_cast<float4 *>(b + 1 * BN * LDK + b_dst) = add4(ga, gb);
+        *reinterpret_cast<float4 *>(b + 2 * BN * LDK + b_dst) = gb;
+    };
+    auto load_a = [&](int kh, int cb) {
 #pragma unroll
-        for (int rb4 = 0; rb4 < 16; rb4 += 4) {
-            int pix[8];
-            float mk[8], rs[8], val[8];
+        for (int j = 0; j < A_LD; ++j) {
+            const bool in = ((a_vh[j] >> kh) & 1u) != 0u;
+            ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, in ? a_off[j] + kh * row4 + cb * 4 : OOB, 0, 0);
+        }
+    };
+    auto store_a = [&](float *a) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = rb4 + q;
-                const int rr = rowq + (r & 3) + 8 * (r >> 2);
-                const int p0 = __shfl(pix_lane, rr, 64);
-                pix[2 * q] = p0;
-                pix[2 * q + 1] = p0 + 1;
-                const float m0 = acc[0][j][r], m1 = acc[1][j][r], m2 = acc[2][j][r], m3 = acc[3][j][r];
-                val[2 * q] = m0 + 0.5f * (m1 + m2);
-                val[2 * q + 1] = 0.5f * (m1 - m2) - m3;
+        for (int j = 0; j < A_LD; ++j) {
+            const float4 v = as_f4(ra[j]);
+            *reinterpret_cast<float4 *>(a + a_dst[j]) = RELU_IN ? relu4(v) : v;
+        }
+    };
+
+    f32x16 acc[3][NT];
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[v][j][r] = 0.f;
+
+    const int frag_row = lane & 31, frag_k = 4 * (lane >> 5);
+    const int lane_a = (wm * 2 * NPH + 2 * frag_row) * LDK + frag_k;     // output row wm of the tile, pair frag_row
+    const int lane_b = (wn * NT * 32 + frag_row) * LDK + frag_k;
+
+    auto compute = [&](const float *a, const float *b, int par) {
+        const float *ap = a + lane_a + par * NPH * LDK;
+        const float4 d0 = *reinterpret_cast<const float4 *>(ap);
+        const float4 d1 = *reinterpret_cast<const float4 *>(ap + LDK);
+        const float4 d2 = *reinterpret_cast<const float4 *>(ap + 2 * LDK);
+        float4 fb[3][NT];
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[v][j] = *reinterpret_cast<const float4 *>(b + (v * BN + j * 32) * LDK + lane_b);
+        float4 fv[3];
+        fv[0] = sub4(d0, d1);
+        fv[1] = d1;
+        fv[2] = sub4(d1, d2);
+#define VQ2_WINO_STEP(C)                                                                                          \
+    _Pragma("unroll") for (int v = 0; v < 3; ++v) _Pragma("unroll") for (int j = 0; j < NT; ++j)                  \
+        acc[v][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[v].C, fb[v][j].C, acc[v][j], 0, 0, 0);
+        VQ2_WINO_STEP(x) VQ2_WINO_STEP(y) VQ2_WINO_STEP(z) VQ2_WINO_STEP(w)
+#undef VQ2_WINO_STEP
+    };
+
+    // ---- prologue: patch (block 0, kernel row 0), taps of its odd parity
+    const int NCB = P.Ci / BK;
+    load_a(0, 0);
+    load_b(0, 0, 0);
+    store_a(As);
+    store_b(Bs);
+    __syncthreads();
+
+    // ---- main loop: patch index ai = (channel block, kernel row); two chunks (parities) per patch
+    int c = 0, ai = 0;
+    for (int cbi = 0; cbi < NCB; ++cbi) {
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh) {
+            const bool last = (cbi == NCB - 1) && (kh == 3);
+            const int nkh = (kh + 1) & 3;
+            const int ncb = (kh == 3 && !last) ? (cbi + 1) * BK : cbi * BK;
+            const int akh = last ? kh : nkh;                       // (the last patch re-loads itself into the idle buffer)
+            const float *a_cur = As + (ai & 1) * A_FLOATS;
+            float *a_nxt = As + ((ai + 1) & 1) * A_FLOATS;
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                if (par == 0) {
+                    load_b(kh, 1, cbi * BK);
+                    load_a(akh, ncb);                              // behind the weight loads, stored a chunk later
+                } else {
+                    load_b(akh, 0, ncb);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                compute(a_cur, Bs + (c & 1) * B3_FLOATS, par);
+                __builtin_amdgcn_sched_barrier(0);
+                store_b(Bs + ((c + 1) & 1) * B3_FLOATS);
+                if (par == 1) store_a(a_nxt);
+                __syncthreads();
+                ++c;
             }
-            if (has_mask) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    mk[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rmk, pix[q] * ldm4 + co4, 0, 0));
-            }
-            if (has_res) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    rs[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, pix[q] * ldr4 + co4, 0, 0));
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                float v = val[q] + bv;
-                if (mask_first) v = (mk[q] > 0.f) ? v : 0.f;
-                if (has_res) v += rs[q];
-                if (mask_last) v = (mk[q] > 0.f) ? v : 0.f;
-                v = relu_floor(v, relu_bits);
-                if (VQ2_WINO_EXP != 6 || v == 123.456f)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, pix[q] * ldy4 + co4, 0, 0);
-            }
+            ++ai;
         }
     }
+
+    const int pix_lane = ((n * P.Ho + h0 + wm) * P.Wo + w0 + 2 * frag_row);
+    store_pairs<NT>(P, n0 + wn * NT * 32, lane, pix_lane, [&](int j, int r, float &y0, float &y1) {
+        const float m1 = acc[0][j][r], m2 = acc[1][j][r], m3 = acc[2][j][r];
+        y0 = m1 + m2;
+        y1 = m2 - m3;
+    });
+}
+
+static int launch_k4s2(const ConvGemmParams &P, hipStream_t s) {
+    auto kern = P.relu_in ? wino_k4s2_kernel<true> : wino_k4s2_kernel<false>;
+    allow_big_lds(kern, k4::LDS_BYTES);
+    const unsigned nwg = (unsigned)(P.N * (P.Ho / 2) * (P.Wo / 64) * (P.Co / BN));
+    const char *name = "conv_wino_k4s2";
+    if (prof_enabled()) name = prof_label("conv_wino_k4s2<2x64>|M=%d,N=%d,K=%d", P.M, P.Co, P.K);
+    ProfScope prof(name, P.flops, P.bytes, s, true);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), k4::LDS_BYTES, s, P);
+    return check_launch("wino_k4s2_kernel");
 }
 
 template <int TPW, int NT>
@@ -274,8 +467,13 @@ static int tune(const char *name, int dflt) {
 // 8-channel input blocks, rows of whole 64-pixel segments, tensors below 1 GiB (32-bit offsets with an additive
 // out-of-range penalty).
 bool wino3_ok(const ConvGemmParams &P) {
-    static const int on = wino::tune("VQ2_WINO", 1);
+    static const int on = wino::tune("VQ2_WINO", 1), on4 = wino::tune("VQ2_WINO_K4", 1);
     const long gib = 1L << 30;
+    if (on4 && P.KH == 4 && P.KW == 4 && P.stride == 2 && P.pad_h == 1 && P.pad_w == 1 && P.phases == 1)   // F(2,2) by parity
+        return 2 * P.Ho == P.H && 2 * P.Wo == P.W && P.Hy == P.Ho && P.Wy == P.Wo && P.Wo % 64 == 0 && P.Ho % 2 == 0 &&
+               P.Ci % wino::BK == 0 && P.Ci >= 32 && P.Co % wino::BN == 0 && P.ldx % 4 == 0 &&
+               (long)P.N * P.H * P.W * P.ldx * 4 < gib && (long)P.N * P.Ho * P.Wo * P.ldy * 4 < gib &&
+               (long)P.N * P.Ho * P.Wo * (P.ldm > P.ldr ? P.ldm : P.ldr) * 4 < gib && (long)P.Co * P.K * 4 < gib;
     return on && P.KH == 3 && P.KW == 3 && P.stride == 1 && P.pad_h == 1 && P.pad_w == 1 && P.phases == 1 &&
            P.Ho == P.H && P.Wo == P.W && P.Hy == P.H && P.Wy == P.W && P.Ci % wino::BK == 0 && P.Ci >= 64 &&
            P.Co % wino::BN == 0 && P.W % 64 == 0 && P.H % 2 == 0 && P.ldx % 4 == 0 &&
@@ -285,6 +483,9 @@ bool wino3_ok(const ConvGemmParams &P) {
 
 // (NT = 1 -- eight waves of 32 pairs x 32 channels, four per SIMD at <= 128 registers -- measured no faster than NT = 2
 //  and does not fit its register budget once the staging loads are held across the MFMA phase; not instantiated.)
-int launch_wino3(const ConvGemmParams &P, hipStream_t s) { return wino::launch<32, 2>(P, s); }
+int launch_wino3(const ConvGemmParams &P, hipStream_t s) {
+    if (P.KH == 4) return wino::launch_k4s2(P, s);
+    return wino::launch<32, 2>(P, s);
+}
 
 }  // namespace vq2
