@@ -60,7 +60,7 @@ def main():
         relu = 0 if os.environ.get("MB_NORELU") else ops.VQ2_RELU_IN
         t_f = timeit(lambda: ops.conv_forward(spec, x, wt, b, relu))
         t_d = timeit(lambda: ops.conv_dgrad(spec, x.shape, dy, wt, mask=None if os.environ.get('MB_NOMASK') else x))
-        t_w = timeit(lambda: ops.conv_wgrad(spec, x, dy, True, wt, b))
+        t_w = timeit(lambda: ops.conv_wgrad(spec, x, dy, not os.environ.get('MB_NORELU'), wt, None if os.environ.get('MB_NOBIAS') else b))
         if os.environ.get("MB_REPEAT"):
             t_f = timeit(lambda: ops.conv_forward(spec, x, wt, b, relu))   # again, after the clocks have settled
         print(f"{name:14s} fwd {t_f:8.1f} us {fl / t_f / 1e6:6.1f} TF | dgrad {t_d:8.1f} us {fl / t_d / 1e6:6.1f} TF | "

@@ -209,6 +209,30 @@ def test_winograd_by_parity_k4s2_conv_forward_and_convT_data_gradient(amd, shape
     F.conv_transpose2d(F.relu(xr), wtt.cpu().double(), None, stride=2, padding=1).backward(dy.permute(0, 3, 1, 2).cpu().double())
     refg = xr.grad.permute(0, 2, 3, 1)
     close(dx.double(), refg, rtol=0, atol=5e-6 * float(refg.abs().max()), what=tag + ".dx")
+    # weight / bias gradients of both layer kinds (64 gathered channels, whole 128-channel tiles): F(2,2) over column pairs
+    if ci == 64 and co % 128 == 0:
+        gy = t(rng.normal(11, tag + ".gy", (n, h // 2, w // 2, co))).to(dev)
+        wr = wt.cpu().double().clone().requires_grad_(True)
+        br = b.cpu().double().clone().requires_grad_(True)
+        for relu_in in (True, False):
+            (dw, db), seen = _launched(amd, lambda: ops.conv_wgrad(spec, x, gy, relu_in, wt, b))
+            assert any(k.startswith("wgrad") and "wino4" in k for k in seen), seen
+            wr.grad = br.grad = None
+            F.conv2d(F.relu(x64) if relu_in else x64, wr, br, stride=2, padding=1).backward(gy.permute(0, 3, 1, 2).cpu().double())
+            close(dw.double(), wr.grad, rtol=0, atol=1e-5 * float(wr.grad.abs().max()), what=tag + ".dw%d" % relu_in)
+            close(db.double(), br.grad, rtol=0, atol=1e-5 * float(br.grad.abs().max()), what=tag + ".db%d" % relu_in)
+        bt = t(rng.uniform(11, tag + ".bt", (ci,), -1, 1)).to(dev)
+        wtr = wtt.cpu().double().clone().requires_grad_(True)
+        btr = bt.cpu().double().clone().requires_grad_(True)
+        xin64 = xin.permute(0, 3, 1, 2).cpu().double()
+        for relu_in in (True, False):
+            (dw, db), seen = _launched(amd, lambda: ops.conv_wgrad(tspec, xin, dy, relu_in, wtt, bt))
+            assert any(k.startswith("wgrad") and "wino4" in k for k in seen), seen
+            wtr.grad = btr.grad = None
+            F.conv_transpose2d(F.relu(xin64) if relu_in else xin64, wtr, btr, stride=2,
+                               padding=1).backward(dy.permute(0, 3, 1, 2).cpu().double())
+            close(dw.double(), wtr.grad, rtol=0, atol=1e-5 * float(wtr.grad.abs().max()), what=tag + ".dwt%d" % relu_in)
+            close(db.double(), btr.grad, rtol=0, atol=1e-5 * float(btr.grad.abs().max()), what=tag + ".dbt%d" % relu_in)
 
 
 def test_layout_conversion_generic_channels(amd):

@@ -255,7 +255,12 @@ __device__ __forceinline__ float4 as_f4w(u32x4w v) {
 // and the reduction kernels finish with  dw[kh][0] = S0 + (S1 + S2)/2, dw[kh][1] = (S1 - S2)/2, dw[kh][2] = (S1 + S2)/2 + S3:
 // 12 products per pair instead of 18 -- 2/3 of the matrix instructions.  A workgroup owns ONE (kh, v, 128-channel block):
 // v is workgroup-uniform, so the transform is one fused multiply-add by +-1 per staged element (exact).
-template <int WAVES_M, int WAVES_N, int MT, int NT, bool RELU_X, bool RELU_G, bool WINO = false>
+// WINO == 2 (4x4 stride-2 pad-1 conv and conv-transpose, I == 64 or I % 128 == 0): the four taps of a kernel row split by
+// column parity into two 2-tap filters (csrc/vq2_wino.hip, wino_k4s2_kernel), each as F(2,2) over output column pairs:
+//     S1 += g0^T (d0 - d1),  S2 += (g0 + g1)^T d1,  S3 += g1^T (d1 - d2);   dw[first tap] = S1 + S2, dw[second] = S2 - S3
+// with d0..d2 = input columns 4t+pc, 4t+pc+2, 4t+pc+4 (pc = -1: taps 0, 2; pc = 0: taps 1, 3): 3/4 of the matrix
+// instructions.  K axis = (v, parity, kh, channel), kh fastest: a 128-wide tile holds two kernel rows of ONE (v, parity).
+template <int WAVES_M, int WAVES_N, int MT, int NT, bool RELU_X, bool RELU_G, int WINO = 0>
 __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
     constexpr int BMO = WAVES_M * MT * 32;
     constexpr int BNK = WAVES_N * NT * 32;
@@ -303,7 +308,9 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
     int nu = 0, xo_a = 0, xo_b = 0, go_a = 0;
     bool g_two = false;
     float sv = -1.f, sg = 1.f;
-    if constexpr (WINO) {
+    bool x_two = true, bias2 = false, bias2u = false;                                  // WINO == 2: V of the middle product is one pixel
+    int par = 0;
+    if constexpr (WINO == 1) {
         const int vt = k0 / P.I;
         kh = vt >> 2; nu = vt & 3; kw = 0;
         ci = x_k - vt * P.I;
@@ -314,6 +321,26 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
         g_two = (nu == 1 || nu == 2);
         sg = (nu == 2) ? -1.f : 1.f;
     }
+    if constexpr (WINO == 2) {
+        const int vt = x_k / P.I;                                       // per thread: the tile may hold two kernel rows
+        const int vt0 = k0 / P.I;
+        kh = vt & 3; par = (vt0 >> 2) & 1; nu = vt0 >> 3; kw = 0;       // nu, par: workgroup-uniform
+        ci = x_k - vt * P.I;
+        const int pc = par ? 0 : -1;
+        xo_a = (nu == 0) ? pc : pc + 2;
+        xo_b = (nu == 0) ? pc + 2 : pc + 4;
+        x_two = nu != 1;
+        sv = -1.f;
+        go_a = (nu == 2) ? 1 : 0;
+        g_two = nu == 1;
+        sg = 1.f;
+        // conv-transpose: the bias gradient is the column sum of the GATHERED operand (dy).  The middle-product tiles read
+        // d1 = columns 4t+1 (odd parity) / 4t+2 (even) of rows 2ho (kh 1) / 2ho+1 (kh 2); with the spare second load on
+        // columns 4t+3 / 4t they visit every dy pixel exactly once.
+        bias2u = P.bias_ws != nullptr && P.bias_taps != 0 && nu == 1 && o0 == 0;   // workgroup-uniform: every thread of
+        bias2 = bias2u && (kh == 1 || kh == 2) && x_kv;                            // such a tile loads and adds, two kernel
+        if (nu == 1) xo_b = par ? 0 : 3;                                           // rows' threads keep their sums
+    }
     int g_const[G_LD], x_const[X_LD], x_iw[X_LD];
 #pragma unroll
     for (int j = 0; j < G_LD; ++j) g_const[j] = ((g_r + j * G_RSTEP) * (WINO ? 2 : 1) * P.ldg + g_c) * 4;
@@ -321,8 +348,9 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
     for (int j = 0; j < X_LD; ++j) {
         const int rj = x_r + j * X_RSTEP;                    // row inside the 32-row chunk
         if constexpr (WINO) {
-            x_iw[j] = 2 * rj;                                // + 2 * pair0 + xo = input column
-            x_const[j] = ((kh * P.W + 2 * rj) * P.ldx + ci) * 4;
+            constexpr int CS = WINO == 2 ? 4 : 2;            // input columns per pair
+            x_iw[j] = CS * rj;                               // + CS * pair0 + xo = input column
+            x_const[j] = ((kh * P.W + CS * rj) * P.ldx + ci) * 4;
         } else {
         x_iw[j] = rj * P.stride - P.pad + kw;                // + wo0*stride = input column
         x_const[j] = ((kh * P.W + kw + rj * P.stride) * P.ldx + ci) * 4;
@@ -341,6 +369,7 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
 
     u32x4w rgv[G_LD], rxv[X_LD];
     u32x4w rgw[WINO ? G_LD : 1], rxw[WINO ? X_LD : 1];       // WINO: the second pixel of every staged element
+    float4 bsum4 = make_float4(0.f, 0.f, 0.f, 0.f);          // WINO == 2, conv-transpose: bias partial of this thread's 4 channels
     auto load_chunk_wino = [&](int mbase) {
         const int rows_left = m_end - mbase;                  // uniform (pairs)
         const int gbase = ((un * P.Ho + uho) * P.Wo + 2 * uwo + go_a) * P.ldg * 4;   // uniform
@@ -350,16 +379,18 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
             rgv[j] = __builtin_amdgcn_raw_buffer_load_b128(rg, v ? gbase + g_const[j] : WOOB, 0, 0);
             rgw[j] = __builtin_amdgcn_raw_buffer_load_b128(rg, (v && g_two) ? gbase + g_const[j] + P.ldg * 4 : WOOB, 0, 0);
         }
-        const int ihu = uho - 1;                               // pad 1
-        const int xbase = ((un * P.H + ihu) * P.W + 2 * uwo) * P.ldx * 4;             // uniform
+        constexpr int CS = WINO == 2 ? 4 : 2;
+        const int ihu = (WINO == 2 ? 2 * uho : uho) - 1;       // pad 1
+        const int xbase = ((un * P.H + ihu) * P.W + CS * uwo) * P.ldx * 4;            // uniform
         const bool hv = x_kv && (unsigned)(ihu + kh) < (unsigned)P.H;
-        const int iwu = 2 * uwo;
+        const int iwu = CS * uwo;
         const int xa = xo_a * P.ldx * 4, xb = xo_b * P.ldx * 4;
+        const bool want_b = x_two || bias2u;
 #pragma unroll
         for (int j = 0; j < X_LD; ++j) {
             const bool v = hv && (x_r + j * X_RSTEP) < rows_left;
             const bool va = v && (unsigned)(iwu + x_iw[j] + xo_a) < (unsigned)P.W;
-            const bool vb = v && (unsigned)(iwu + x_iw[j] + xo_b) < (unsigned)P.W;
+            const bool vb = v && want_b && (unsigned)(iwu + x_iw[j] + xo_b) < (unsigned)P.W;
             rxv[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, va ? xbase + x_const[j] + xa : WOOB, 0, 0);
             rxw[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, vb ? xbase + x_const[j] + xb : WOOB, 0, 0);
         }
@@ -400,13 +431,15 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
 #pragma unroll
         for (int j = 0; j < G_LD; ++j) {
             float4 v = as_f4w(rgv[j]);
+            if (RELU_G) v = relu4(v);
             if constexpr (WINO) {
                 if (g_two) {                                   // workgroup-uniform
-                    const float4 w = as_f4w(rgw[j]);
+                    float4 w = as_f4w(rgw[j]);
+                    if (RELU_G) w = relu4(w);
                     v = make_float4(fmaf(sg, w.x, v.x), fmaf(sg, w.y, v.y), fmaf(sg, w.z, v.z), fmaf(sg, w.w, v.w));
                 }
             }
-            *reinterpret_cast<float4 *>(gs + (g_r + j * G_RSTEP) * BMO + (tid % G_C4) * 4) = RELU_G ? relu4(v) : v;
+            *reinterpret_cast<float4 *>(gs + (g_r + j * G_RSTEP) * BMO + (tid % G_C4) * 4) = v;
         }
 #pragma unroll
         for (int j = 0; j < X_LD; ++j) {
@@ -414,7 +447,11 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
             if constexpr (WINO) {
                 float4 w = as_f4w(rxw[j]);
                 if (RELU_X) { v = relu4(v); w = relu4(w); }
-                v = make_float4(fmaf(sv, w.x, v.x), fmaf(sv, w.y, v.y), fmaf(sv, w.z, v.z), fmaf(sv, w.w, v.w));
+                if (WINO == 2 && bias2u) {                     // (rows past the split and out-of-range pixels were read as 0)
+                    bsum4.x += v.x + w.x; bsum4.y += v.y + w.y; bsum4.z += v.z + w.z; bsum4.w += v.w + w.w;
+                }
+                if (WINO == 1 || x_two)                        // x_two: workgroup-uniform
+                    v = make_float4(fmaf(sv, w.x, v.x), fmaf(sv, w.y, v.y), fmaf(sv, w.z, v.z), fmaf(sv, w.w, v.w));
                 *reinterpret_cast<float4 *>(xs + (x_r + j * X_RSTEP) * BNK + (tid % X_C4) * 4) = v;
             } else {
             if (X_C4 * X_RSTEP == 256 || x_act)
@@ -439,11 +476,12 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
     __syncthreads();
     const int fr = lane & 31, fk = lane >> 5;
     // (WINO: the tile (kh 0, v 1) stages E = g0 + g1 -- its column sums over the pairs are the sums over the pixels)
-    const bool do_bias = P.bias_ws != nullptr && !P.bias_taps && k0 == (WINO ? P.I : 0) && tid < BMO;
+    // (WINO == 2: the tile (v 1, parity 0, kh 0..1) likewise)
+    const bool do_bias = P.bias_ws != nullptr && !P.bias_taps && k0 == (WINO == 2 ? 8 * P.I : WINO == 1 ? P.I : 0) && tid < BMO;
     // exchanged roles: dy is the gathered operand; its centre tap visits every pixel exactly once, so the
     // column sums of that k-block of the staged X tile are the bias gradient (tile width == one tap)
     int bx_col = -1;   // this thread's slot in a bias_ws row when its k column belongs to a bias tap
-    if (P.bias_ws != nullptr && P.bias_taps && o0 == 0 && tid < BNK && k0 + tid < P.K) {
+    if (WINO == 0 && P.bias_ws != nullptr && P.bias_taps && o0 == 0 && tid < BNK && k0 + tid < P.K) {
         const int tap = (k0 + tid) / P.I;
         if ((P.bias_taps >> tap) & 1) bx_col = __popc(P.bias_taps & ((1u << tap) - 1u)) * P.I + (k0 + tid - tap * P.I);
     }
@@ -501,6 +539,25 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
     }
     if (do_bias && o0 + tid < P.O) P.bias_ws[(size_t)split * P.O + o0 + tid] = bsum;
     if (do_bias_x) P.bias_ws[(size_t)split * P.bias_nslots * P.I + bx_col] = bsum;
+    if constexpr (WINO == 2) {
+        // the eight staging row groups meet in LDS (fixed order); 4 slots per split: (parity, kernel row 1 | 2) -- the
+        // reduction kernel adds all S * 4 of them (a long slot list is a long chain of dependent loads there)
+        if (bias2u) {                                      // workgroup-uniform
+            float4 *red = reinterpret_cast<float4 *>(Xs);  // (the main loop ended with a barrier: the tiles are free)
+            red[tid] = bsum4;
+            __syncthreads();
+            if (bias2 && x_r == 0) {
+                float4 t = red[tid];
+#pragma unroll
+                for (int r = 1; r < 8; ++r) {
+                    const float4 u = red[r * X_C4 + tid];
+                    t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+                }
+                const int slot = par * 2 + (kh - 1);
+                *reinterpret_cast<float4 *>(P.bias_ws + ((size_t)split * 4 + slot) * P.I + ci) = t;
+            }
+        }
+    }
 
     float *slab = P.ws + (size_t)split * P.O * P.K;
     const int colq = lane & 31, rowq = 4 * (lane >> 5);
@@ -520,6 +577,57 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
     }
 }
 
+// Winograd slabs (wgrad_fast_kernel<..., WINO>) -> reference layout.  mode 1: [S][O][(kh 3, v 4, i)], one thread column per
+// (o, kh, i), three taps out; mode 2: [S][O][(v 3, parity 2, kh 4, i)], one column per (o, parity, kh, i), two taps out.
+// Same fixed order as the plain reduction: split lane g adds splits g, g+8, ...; the 8 partials are added in lane order.
+__device__ __forceinline__ void wino_reduce_unit(int mode, int t, int lane, int g, const float *__restrict__ ws,
+                                                 float *__restrict__ dw, int O, int I, int Or, int Ir, int S,
+                                                 float (*part4)[8][33]) {
+    const int nv = mode == 1 ? 4 : 3, ntap = mode == 1 ? 9 : 16;
+    const int KW_ = (mode == 1 ? 12 : 24) * I, stride = O * KW_;
+    const int per_o = (mode == 1 ? 3 : 8) * I, cols = O * per_o;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    int o = 0, q = 0, i = 0;     // q = kh (mode 1) or parity * 4 + kh (mode 2)
+    if (t < cols) {
+        o = t / per_o;
+        const int r = t - o * per_o;
+        q = r / I; i = r - q * I;
+        // column of v: mode 1 (kh * 4 + v) * I + i; mode 2 ((v * 2 + parity) * 4 + kh) * I + i = (v * 8 + q) * I + i
+        const float *src = ws + (size_t)o * KW_ + (mode == 1 ? q * 4 * I : q * I) + i;
+        const int vstep = mode == 1 ? I : 8 * I;
+        for (int z = g; z < S; z += 8) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if (v < nv) s[v] += src[(size_t)z * stride + v * vstep];
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) part4[v][g][lane] = s[v];
+    __syncthreads();
+    if (g == 0 && t < cols && o < Or && i < Ir) {
+        float r4[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            float a = part4[v][0][lane];
+#pragma unroll
+            for (int qq = 1; qq < 8; ++qq) a += part4[v][qq][lane];
+            r4[v] = a;
+        }
+        float *dst = dw + ((size_t)o * Ir + i) * ntap;
+        if (mode == 1) {
+            const float h = 0.5f * (r4[1] + r4[2]);
+            dst[q * 3 + 0] = r4[0] + h;
+            dst[q * 3 + 1] = 0.5f * (r4[1] - r4[2]);
+            dst[q * 3 + 2] = h + r4[3];
+        } else {
+            const int par = q >> 2, kh = q & 3;
+            dst[kh * 4 + par] = r4[0] + r4[1];          // taps 0 / 1
+            dst[kh * 4 + par + 2] = r4[1] - r4[2];      // taps 2 / 3
+        }
+    }
+    __syncthreads();
+}
+
 // Sum the slabs and scatter [o][tap][i] (padded O x I) -> reference layout [Or][Ir][tap].
 // 256 threads = 32 outputs x 8 split-lanes: lane g adds splits g, g+8, ... (4 loads in flight), the 8
 // partial sums are combined through LDS in a fixed order -> bit-reproducible, and latency is paid
@@ -530,46 +638,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
                                                            int swapped, int bias_splits) {
     __shared__ float part[8][33];
     const int lane = threadIdx.x & 31, g = threadIdx.x >> 5;
-    if (swapped & 2) {   // Winograd slabs [S][O][(kh, v, i)] -> dw[o][i][kh][0..2]; one thread column per (o, kh, i)
-        __shared__ float part4[4][8][33];
-        const int KW_ = 12 * I, stride = O * KW_, cols = O * 3 * I;
-        for (int base = blockIdx.x * 32; base < cols; base += gridDim.x * 32) {
-            const int t = base + lane;
-            float s[4] = {0.f, 0.f, 0.f, 0.f};
-            int o = 0, kh = 0, i = 0;
-            if (t < cols) {
-                o = t / (3 * I);
-                const int r = t - o * 3 * I;
-                kh = r / I; i = r - kh * I;
-                const float *src = ws + (size_t)o * KW_ + (kh * 4) * I + i;
-                for (int z = g; z < S; z += 8) {
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) s[v] += src[(size_t)z * stride + v * I];
-                }
-            }
-#pragma unroll
-            for (int v = 0; v < 4; ++v) part4[v][g][lane] = s[v];
-            __syncthreads();
-            if (g == 0 && t < cols && o < Or && i < Ir) {
-                float r4[4];
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    float a = part4[v][0][lane];
-#pragma unroll
-                    for (int q = 1; q < 8; ++q) a += part4[v][q][lane];
-                    r4[v] = a;
-                }
-                float *dst = dw + ((size_t)o * Ir + i) * 9 + kh * 3;
-                const float h = 0.5f * (r4[1] + r4[2]);
-                dst[0] = r4[0] + h;
-                dst[1] = 0.5f * (r4[1] - r4[2]);
-                dst[2] = h + r4[3];
-            }
-            __syncthreads();
-        }
+    __shared__ float part4[4][8][33];
+    const int wmode = (swapped >> 1) & 3;     // 0 plain, 1 F(2,3) rows, 2 F(2,2) by parity
+    if (wmode) {
+        const int cols = O * (wmode == 1 ? 3 : 8) * I;
+        for (int base = blockIdx.x * 32; base < cols; base += gridDim.x * 32)
+            wino_reduce_unit(wmode, base + lane, lane, g, ws, dw, O, I, Or, Ir, S, part4);
     }
     const int K = taps * I;
-    const int total = (swapped & 2) ? 0 : O * K;
+    const int total = wmode ? 0 : O * K;
     swapped &= 1;
     for (int base = blockIdx.x * 32; base < total; base += gridDim.x * 32) {
         const int t = base + lane;
@@ -639,40 +716,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const vq2_wgr
         const vq2_wgrad_job j = jobs[lo];
         const int lu = (int)(u - j.unit_offset);
         const bool is_bias = lu >= j.n_units_w;
-        if ((j.swapped & 2) && !is_bias) {   // Winograd slabs (see wgrad_reduce_kernel): unit = 32 columns (o, kh, i)
-            const int KW_ = 12 * j.I, stride = j.O * KW_, cols = j.O * 3 * j.I;
-            const int t = lu * 32 + lane;
-            float s[4] = {0.f, 0.f, 0.f, 0.f};
-            int o = 0, kh = 0, i = 0;
-            if (t < cols) {
-                o = t / (3 * j.I);
-                const int r = t - o * 3 * j.I;
-                kh = r / j.I; i = r - kh * j.I;
-                const float *src = j.ws + (size_t)o * KW_ + (kh * 4) * j.I + i;
-                for (int z = g; z < j.S; z += 8) {
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) s[v] += src[(size_t)z * stride + v * j.I];
-                }
-            }
-#pragma unroll
-            for (int v = 0; v < 4; ++v) part4[v][g][lane] = s[v];
-            __syncthreads();
-            if (g == 0 && t < cols && o < j.Or && i < j.Ir) {
-                float r4[4];
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    float a = part4[v][0][lane];
-#pragma unroll
-                    for (int q = 1; q < 8; ++q) a += part4[v][q][lane];
-                    r4[v] = a;
-                }
-                float *dst = j.dw + ((size_t)o * j.Ir + i) * 9 + kh * 3;
-                const float h = 0.5f * (r4[1] + r4[2]);
-                dst[0] = r4[0] + h;
-                dst[1] = 0.5f * (r4[1] - r4[2]);
-                dst[2] = h + r4[3];
-            }
-            __syncthreads();
+        if ((j.swapped & 6) && !is_bias) {   // Winograd slabs: unit = 32 thread columns (wino_reduce_unit)
+            wino_reduce_unit((j.swapped >> 1) & 3, lu * 32 + lane, lane, g, j.ws, j.dw, j.O, j.I, j.Or, j.Ir, j.S, part4);
             continue;
         }
         const int K = j.taps * j.I;
@@ -750,6 +795,18 @@ static WgradPlan plan_wgrad(const vq2_conv_desc *d) {
         p.K = 12 * p.I;
         p.M = p.M / 2;
     }
+    static const int wwino4 = getenv("VQ2_WWINO_K4") ? atoi(getenv("VQ2_WWINO_K4")) : 1;
+    {   // 4x4 stride-2 conv / conv-transpose: F(2,2) by column parity over output column pairs
+        const int wo = d->transposed ? d->W : d->W / 2;       // width of the G operand's grid
+        if (wwino4 && wfast && !p.swapped && d->KH == 4 && d->KW == 4 && d->stride == 2 && d->pad == 1 && d->H % 2 == 0 &&
+            d->W % 2 == 0 && p.O % 128 == 0 && (p.I == 64 || p.I % 128 == 0) && wo % 64 == 0 &&
+            (long)d->N * d->H * d->W * d->ldx < (1L << 29) &&
+            (long)d->N * d->H * d->W * d->ldy * (d->transposed ? 4 : 1) < (1L << 29)) {
+            p.wino = 2;
+            p.K = 24 * p.I;
+            p.M = p.M / 2;
+        }
+    }
     // output tile (o x k): the candidate that wastes the least padded work, larger tile on ties
     // 128 x 96 = one kernel row of a 3x3 conv with 32 gathered channels (the ResBlock weight gradient with
     // exchanged roles, K = 288): 48 MFMAs per wave and chunk instead of 16 for the same staging
@@ -783,6 +840,7 @@ static WgradPlan plan_wgrad(const vq2_conv_desc *d) {
 // one per output phase, never out of bounds.
 static void bias_taps_of(const vq2_conv_desc *d, const WgradPlan &p, int &taps, int &nslots) {
     taps = 0; nslots = 0;
+    if (p.wino == 2 && d->transposed) { taps = 1; nslots = 4; return; }    // flag only: see wgrad_fast_kernel<..., 2>
     if (p.swapped) { taps = 1 << ((d->KH / 2) * d->KW + d->KW / 2); nslots = 1; }
     else if (d->transposed) { taps = (1 << 5) | (1 << 6) | (1 << 9) | (1 << 10); nslots = 4; }
 }
@@ -944,10 +1002,13 @@ static int wgrad_impl(const vq2_conv_desc *d, int flags, const float *x, const f
     const double pix_out_ = d->transposed ? 4.0 * pix_in_ : (double)P.M * (p.wino ? 2.0 : 1.0);
     const double macs_ = d->transposed ? pix_in_ * 16.0 * cir_ * cor_ : pix_out_ * d->KH * d->KW * cir_ * cor_;
     const char *pname = "wgrad";
-    if (prof_enabled()) pname = prof_label("wgrad<%dx%d>%s|O=%d,K=%d,M=%d,S=%d,k%d", p.bmo, p.bnk, p.swapped ? "sw" : (p.wino ? "wino" : ""), p.O, p.K, p.M, p.S, d->KH);
+    if (prof_enabled()) pname = prof_label("wgrad<%dx%d>%s|O=%d,K=%d,M=%d,S=%d,k%d", p.bmo, p.bnk, p.swapped ? "sw" : (p.wino == 1 ? "wino" : p.wino == 2 ? "wino4" : ""), p.O, p.K, p.M, p.S, d->KH);
     ProfScope prof(pname, 2.0 * macs_, 4.0 * (pix_in_ * cir_ + pix_out_ * cor_ + cir_ * cor_ * d->KH * d->KW), s);
     if (p.wino) {
-        auto kern = P.relu_x ? wgrad_fast_kernel<2, 2, 2, 2, true, false, true> : wgrad_fast_kernel<2, 2, 2, 2, false, false, true>;
+        auto kern = P.relu_x ? wgrad_fast_kernel<2, 2, 2, 2, true, false, 1> : wgrad_fast_kernel<2, 2, 2, 2, false, false, 1>;
+        if (p.wino == 2)
+            kern = P.relu_x ? wgrad_fast_kernel<2, 2, 2, 2, true, false, 2>
+                            : (P.relu_g ? wgrad_fast_kernel<2, 2, 2, 2, false, true, 2> : wgrad_fast_kernel<2, 2, 2, 2, false, false, 2>);
         const size_t lds = (size_t)2 * WG_BKR * 256 * sizeof(float);
         allow_big_lds(kern, lds);
         hipLaunchKernelGGL(kern, dim3((P.K / 128) * ((P.O + 127) / 128) * p.S), dim3(256), lds, s, P);
@@ -990,7 +1051,7 @@ extern "C" int vq2_wgrad_job_init(const vq2_conv_desc *d, const void *ws, float 
     job->O = p.O; job->I = p.I; job->Or = sw ? cir : cor; job->Ir = sw ? cor : cir;
     job->swapped = p.swapped | (p.wino << 1); job->bias_splits = 0;
     job->taps = d->KH * d->KW; job->S = p.S;
-    job->n_units_w = p.wino ? (p.O * 3 * p.I + 31) / 32 : (p.O * p.K + 31) / 32;
+    job->n_units_w = p.wino ? (p.O * (p.wino == 1 ? 3 : 8) * p.I + 31) / 32 : (p.O * p.K + 31) / 32;
     job->n_units_b = 0;
     if (db) {
         int taps, nslots;

@@ -226,11 +226,11 @@ __global__ __launch_bounds__(128 * (4 / NT), NT == 1 ? 4 : 2) void wino3_kernel(
             const int nkh = (kh + 1) % 3;
             const int ncb = (kh == 2) ? cbn : cbi;
             if (VQ2_WINO_EXP != 1 && VQ2_WINO_EXP != 2) {
-                if (role_b) load_b(nkh, ncb * BK);
+                if (role_b && VQ2_WINO_EXP != 8) load_b(nkh, ncb * BK);
                 // the next block's patch: issued BEHIND the weight loads of kernel row 0 and stored a chunk later, so that an
                 // activation line that has to come from HBM has two chunks of time and never holds up the weight tile
                 // (loads return in order: waiting for a younger load waits for every older one)
-                if (kh == 0) {
+                if (kh == 0 && VQ2_WINO_EXP != 7) {
 #pragma unroll
                     for (int j = 0; j < A_LD; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, a_off[j] + cbn * BK * 4, 0, 0);
                 }
