@@ -235,6 +235,35 @@ def test_winograd_by_parity_k4s2_conv_forward_and_convT_data_gradient(amd, shape
             close(db.double(), btr.grad, rtol=0, atol=1e-5 * float(btr.grad.abs().max()), what=tag + ".dbt%d" % relu_in)
 
 
+@pytest.mark.parametrize("shape", [(2, 6, 64, 128), (1, 5, 128, 128), (3, 3, 64, 256)])
+def test_winograd_exchanged_roles_weight_gradient_of_the_resblock_3x3(amd, shape):
+    """The 3x3 conv into 32 channels (ResBlock, vqvae.py:87) has its weight gradient computed with the roles of x and dy
+    exchanged; on rows of whole 64-pixel segments that sum runs as F(2,3) over column pairs (wgrad_fast_kernel<..., 3>).
+    dw and db (taken from the gathered dy operand) with and without the fused ReLU on x, through channel slices, vs fp64."""
+    from vqvae2_amd import ops
+    dev = torch.device("cuda:0")
+    n, h, w, ci = shape
+    co = 32
+    tag = "swwino%dx%dx%d" % (h, w, ci)
+    wide_in = t(rng.normal(13, tag + ".in", (n, h, w, ci + 8))).to(dev)
+    x = wide_in[..., 4:4 + ci]
+    wide_dy = t(rng.normal(13, tag + ".dy", (n, h, w, co + 4))).to(dev)
+    dy = wide_dy[..., 4:4 + co]
+    wt = t(rng.uniform(13, tag + ".w", (co, ci, 3, 3), -0.1, 0.1)).to(dev)
+    b = t(rng.uniform(13, tag + ".b", (co,), -1, 1)).to(dev)
+    spec = ops.ConvSpec(False, ci, co, 3, 1, 1)
+    x64 = x.permute(0, 3, 1, 2).cpu().double()
+    wr = wt.cpu().double().clone().requires_grad_(True)
+    br = b.cpu().double().clone().requires_grad_(True)
+    for relu_in in (True, False):
+        (dw, db), seen = _launched(amd, lambda: ops.conv_wgrad(spec, x, dy, relu_in, wt, b))
+        assert any(k.startswith("wgrad") and "swwino" in k for k in seen), seen
+        wr.grad = br.grad = None
+        F.conv2d(F.relu(x64) if relu_in else x64, wr, br, padding=1).backward(dy.permute(0, 3, 1, 2).cpu().double())
+        close(dw.double(), wr.grad, rtol=0, atol=1e-5 * float(wr.grad.abs().max()), what=tag + ".dw%d" % relu_in)
+        close(db.double(), br.grad, rtol=0, atol=1e-5 * float(br.grad.abs().max()), what=tag + ".db%d" % relu_in)
+
+
 def test_layout_conversion_generic_channels(amd):
     from vqvae2_amd import ops
     dev = torch.device("cuda:0")

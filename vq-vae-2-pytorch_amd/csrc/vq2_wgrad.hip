@@ -260,6 +260,9 @@ __device__ __forceinline__ float4 as_f4w(u32x4w v) {
 //     S1 += g0^T (d0 - d1),  S2 += (g0 + g1)^T d1,  S3 += g1^T (d1 - d2);   dw[first tap] = S1 + S2, dw[second] = S2 - S3
 // with d0..d2 = input columns 4t+pc, 4t+pc+2, 4t+pc+4 (pc = -1: taps 0, 2; pc = 0: taps 1, 3): 3/4 of the matrix
 // instructions.  K axis = (v, parity, kh, channel), kh fastest: a 128-wide tile holds two kernel rows of ONE (v, parity).
+// WINO == 3 (the exchanged-roles form of a 3x3 conv with 32 output channels -- the ResBlock 3x3 -- on 128 x 96 tiles): the
+// STREAMED operand is x and carries V_v (two pixels of the row, with column checks), the gathered operand is dy and carries
+// E_v at the three row shifts 1 - kh: S_v[kh] += V_v[r]^T E_v[r - kh + 1].  K axis = (v, kh, co); a tile is one v.
 template <int WAVES_M, int WAVES_N, int MT, int NT, bool RELU_X, bool RELU_G, int WINO = 0>
 __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
     constexpr int BMO = WAVES_M * MT * 32;
@@ -341,6 +344,20 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
         bias2 = bias2u && (kh == 1 || kh == 2) && x_kv;                            // such a tile loads and adds, two kernel
         if (nu == 1) xo_b = par ? 0 : 3;                                           // rows' threads keep their sums
     }
+    int go_b = 1;                                                      // WINO == 3: second pixel of V on the streamed side
+    if constexpr (WINO == 3) {
+        nu = k0 / BNK;                                                  // workgroup-uniform (one v per 96-wide tile)
+        const int kl = x_k - k0;
+        kh = kl / P.I; kw = 0; ci = kl - kh * P.I;                      // kh: per thread (three kernel rows per tile)
+        go_a = (nu == 0) ? -1 : (nu == 1) ? 0 : (nu == 2) ? 1 : 2;     // V = x[a] + sg * x[b]
+        go_b = (nu == 0) ? 1 : (nu == 1) ? 1 : 0;
+        g_two = true;
+        sg = (nu == 1) ? 1.f : -1.f;
+        xo_a = (nu == 3) ? 1 : 0;                                       // E = dy[a] (+ sv * dy[1])
+        xo_b = 1;
+        x_two = (nu == 1 || nu == 2);
+        sv = (nu == 2) ? -1.f : 1.f;
+    }
     int g_const[G_LD], x_const[X_LD], x_iw[X_LD];
 #pragma unroll
     for (int j = 0; j < G_LD; ++j) g_const[j] = ((g_r + j * G_RSTEP) * (WINO ? 2 : 1) * P.ldg + g_c) * 4;
@@ -350,7 +367,7 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
         if constexpr (WINO) {
             constexpr int CS = WINO == 2 ? 4 : 2;            // input columns per pair
             x_iw[j] = CS * rj;                               // + CS * pair0 + xo = input column
-            x_const[j] = ((kh * P.W + CS * rj) * P.ldx + ci) * 4;
+            x_const[j] = (((WINO == 3 ? -kh : kh) * P.W + CS * rj) * P.ldx + ci) * 4;
         } else {
         x_iw[j] = rj * P.stride - P.pad + kw;                // + wo0*stride = input column
         x_const[j] = ((kh * P.W + kw + rj * P.stride) * P.ldx + ci) * 4;
@@ -376,13 +393,21 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
 #pragma unroll
         for (int j = 0; j < G_LD; ++j) {
             const bool v = g_cv && (g_r + j * G_RSTEP) < rows_left;
+            if constexpr (WINO == 3) {                         // (gbase carries go_a; the second pixel is go_b - go_a further)
+                const int col = 2 * (uwo + g_r + j * G_RSTEP);
+                const bool va = v && (unsigned)(col + go_a) < (unsigned)P.Wo;
+                const bool vb = v && (unsigned)(col + go_b) < (unsigned)P.Wo;
+                rgv[j] = __builtin_amdgcn_raw_buffer_load_b128(rg, va ? gbase + g_const[j] : WOOB, 0, 0);
+                rgw[j] = __builtin_amdgcn_raw_buffer_load_b128(rg, vb ? gbase + g_const[j] + (go_b - go_a) * P.ldg * 4 : WOOB, 0, 0);
+            } else {
             rgv[j] = __builtin_amdgcn_raw_buffer_load_b128(rg, v ? gbase + g_const[j] : WOOB, 0, 0);
             rgw[j] = __builtin_amdgcn_raw_buffer_load_b128(rg, (v && g_two) ? gbase + g_const[j] + P.ldg * 4 : WOOB, 0, 0);
+            }
         }
         constexpr int CS = WINO == 2 ? 4 : 2;
-        const int ihu = (WINO == 2 ? 2 * uho : uho) - 1;       // pad 1
+        const int ihu = WINO == 3 ? uho + 1 : (WINO == 2 ? 2 * uho : uho) - 1;   // pad 1 (WINO 3: row shift 1 - kh)
         const int xbase = ((un * P.H + ihu) * P.W + CS * uwo) * P.ldx * 4;            // uniform
-        const bool hv = x_kv && (unsigned)(ihu + kh) < (unsigned)P.H;
+        const bool hv = x_kv && (unsigned)(ihu + (WINO == 3 ? -kh : kh)) < (unsigned)P.H;
         const int iwu = CS * uwo;
         const int xa = xo_a * P.ldx * 4, xb = xo_b * P.ldx * 4;
         const bool want_b = x_two || bias2u;
@@ -452,7 +477,8 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
                 }
                 if (WINO == 1 || x_two)                        // x_two: workgroup-uniform
                     v = make_float4(fmaf(sv, w.x, v.x), fmaf(sv, w.y, v.y), fmaf(sv, w.z, v.z), fmaf(sv, w.w, v.w));
-                *reinterpret_cast<float4 *>(xs + (x_r + j * X_RSTEP) * BNK + (tid % X_C4) * 4) = v;
+                if (X_C4 * X_RSTEP == 256 || x_act)
+                    *reinterpret_cast<float4 *>(xs + (x_r + j * X_RSTEP) * BNK + (tid % X_C4) * 4) = v;
             } else {
             if (X_C4 * X_RSTEP == 256 || x_act)
                 *reinterpret_cast<float4 *>(xs + (x_r + j * X_RSTEP) * BNK + (tid % X_C4) * 4) = RELU_X ? relu4(v) : v;
@@ -481,6 +507,8 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
     // exchanged roles: dy is the gathered operand; its centre tap visits every pixel exactly once, so the
     // column sums of that k-block of the staged X tile are the bias gradient (tile width == one tap)
     int bx_col = -1;   // this thread's slot in a bias_ws row when its k column belongs to a bias tap
+    if (WINO == 3 && P.bias_ws != nullptr && P.bias_taps && o0 == 0 && k0 == BNK && tid >= P.I && tid < 2 * P.I)
+        bx_col = tid - P.I;        // tile v = 1 stages E = dy0 + dy1; its kh = 1 columns (row shift 0) see every dy row once
     if (WINO == 0 && P.bias_ws != nullptr && P.bias_taps && o0 == 0 && tid < BNK && k0 + tid < P.K) {
         const int tap = (k0 + tid) / P.I;
         if ((P.bias_taps >> tap) & 1) bx_col = __popc(P.bias_taps & ((1u << tap) - 1u)) * P.I + (k0 + tid - tap * P.I);
@@ -578,14 +606,15 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
 }
 
 // Winograd slabs (wgrad_fast_kernel<..., WINO>) -> reference layout.  mode 1: [S][O][(kh 3, v 4, i)], one thread column per
-// (o, kh, i), three taps out; mode 2: [S][O][(v 3, parity 2, kh 4, i)], one column per (o, parity, kh, i), two taps out.
+// (o, kh, i), three taps out; mode 2: [S][O][(v 3, parity 2, kh 4, i)], one column per (o, parity, kh, i), two taps out;
+// mode 3: [S][O = ci][(v 4, kh 3, i = co)], as mode 1 into the transposed destination.
 // Same fixed order as the plain reduction: split lane g adds splits g, g+8, ...; the 8 partials are added in lane order.
 __device__ __forceinline__ void wino_reduce_unit(int mode, int t, int lane, int g, const float *__restrict__ ws,
                                                  float *__restrict__ dw, int O, int I, int Or, int Ir, int S,
                                                  float (*part4)[8][33]) {
-    const int nv = mode == 1 ? 4 : 3, ntap = mode == 1 ? 9 : 16;
-    const int KW_ = (mode == 1 ? 12 : 24) * I, stride = O * KW_;
-    const int per_o = (mode == 1 ? 3 : 8) * I, cols = O * per_o;
+    const int nv = mode == 2 ? 3 : 4, ntap = mode == 2 ? 16 : 9;
+    const int KW_ = (mode == 2 ? 24 : 12) * I, stride = O * KW_;
+    const int per_o = (mode == 2 ? 8 : 3) * I, cols = O * per_o;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     int o = 0, q = 0, i = 0;     // q = kh (mode 1) or parity * 4 + kh (mode 2)
     if (t < cols) {
@@ -593,8 +622,9 @@ __device__ __forceinline__ void wino_reduce_unit(int mode, int t, int lane, int 
         const int r = t - o * per_o;
         q = r / I; i = r - q * I;
         // column of v: mode 1 (kh * 4 + v) * I + i; mode 2 ((v * 2 + parity) * 4 + kh) * I + i = (v * 8 + q) * I + i
+        // mode 3 (exchanged roles, slab rows = input channels): (v * 3 + kh) * I + i
         const float *src = ws + (size_t)o * KW_ + (mode == 1 ? q * 4 * I : q * I) + i;
-        const int vstep = mode == 1 ? I : 8 * I;
+        const int vstep = mode == 1 ? I : (mode == 2 ? 8 : 3) * I;
         for (int z = g; z < S; z += 8) {
 #pragma unroll
             for (int v = 0; v < 4; ++v)
@@ -613,8 +643,8 @@ __device__ __forceinline__ void wino_reduce_unit(int mode, int t, int lane, int 
             for (int qq = 1; qq < 8; ++qq) a += part4[v][qq][lane];
             r4[v] = a;
         }
-        float *dst = dw + ((size_t)o * Ir + i) * ntap;
-        if (mode == 1) {
+        float *dst = dw + (mode == 3 ? (size_t)i * Or + o : (size_t)o * Ir + i) * ntap;
+        if (mode != 2) {
             const float h = 0.5f * (r4[1] + r4[2]);
             dst[q * 3 + 0] = r4[0] + h;
             dst[q * 3 + 1] = 0.5f * (r4[1] - r4[2]);
@@ -641,13 +671,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     __shared__ float part4[4][8][33];
     const int wmode = (swapped >> 1) & 3;     // 0 plain, 1 F(2,3) rows, 2 F(2,2) by parity
     if (wmode) {
-        const int cols = O * (wmode == 1 ? 3 : 8) * I;
+        const int cols = O * (wmode == 2 ? 8 : 3) * I;
         for (int base = blockIdx.x * 32; base < cols; base += gridDim.x * 32)
             wino_reduce_unit(wmode, base + lane, lane, g, ws, dw, O, I, Or, Ir, S, part4);
     }
     const int K = taps * I;
     const int total = wmode ? 0 : O * K;
-    swapped &= 1;
+    swapped = wmode ? 0 : (swapped & 1);
     for (int base = blockIdx.x * 32; base < total; base += gridDim.x * 32) {
         const int t = base + lane;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -786,6 +816,7 @@ static WgradPlan plan_wgrad(const vq2_conv_desc *d) {
     }
     p.K = d->KH * d->KW * p.I;
     p.wino = 0;
+    static const int wwino3 = getenv("VQ2_WWINO_SW") ? atoi(getenv("VQ2_WWINO_SW")) : 1;
     static const int wwino = getenv("VQ2_WWINO") ? atoi(getenv("VQ2_WWINO")) : 1;
     static const int wfast = getenv("VQ2_WFAST") ? atoi(getenv("VQ2_WFAST")) : 1;
     if (wwino && wfast && !p.swapped && !d->transposed && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 &&
@@ -819,6 +850,13 @@ static WgradPlan plan_wgrad(const vq2_conv_desc *d) {
         const long pk = (p.K + cand[c][1] - 1) / cand[c][1] * cand[c][1];
         const long work = po * pk;
         if (best < 0 || work < best) { best = work; p.bmo = cand[c][0]; p.bnk = cand[c][1]; }
+    }
+    if (wwino3 && wfast && p.swapped && d->KH == 3 && d->pad == 1 && p.I == 32 && p.O % 128 == 0 && d->W % 64 == 0 &&
+        (long)d->N * d->H * d->W * d->ldx < (1L << 29) && (long)d->N * d->H * d->W * d->ldy < (1L << 29)) {
+        p.wino = 3;                 // exchanged roles + F(2,3): four 128 x 96 tiles (v) of three kernel rows each
+        p.K = 4 * 96;
+        p.M = p.M / 2;
+        p.bmo = 128; p.bnk = 96;
     }
     const int tiles = ((p.K + p.bnk - 1) / p.bnk) * ((p.O + p.bmo - 1) / p.bmo);
     const int lds = 2 * WG_BKR * (p.bmo + p.bnk) * 4;
@@ -1002,9 +1040,15 @@ static int wgrad_impl(const vq2_conv_desc *d, int flags, const float *x, const f
     const double pix_out_ = d->transposed ? 4.0 * pix_in_ : (double)P.M * (p.wino ? 2.0 : 1.0);
     const double macs_ = d->transposed ? pix_in_ * 16.0 * cir_ * cor_ : pix_out_ * d->KH * d->KW * cir_ * cor_;
     const char *pname = "wgrad";
-    if (prof_enabled()) pname = prof_label("wgrad<%dx%d>%s|O=%d,K=%d,M=%d,S=%d,k%d", p.bmo, p.bnk, p.swapped ? "sw" : (p.wino == 1 ? "wino" : p.wino == 2 ? "wino4" : ""), p.O, p.K, p.M, p.S, d->KH);
+    if (prof_enabled()) pname = prof_label("wgrad<%dx%d>%s|O=%d,K=%d,M=%d,S=%d,k%d", p.bmo, p.bnk, p.wino == 3 ? "swwino" : p.swapped ? "sw" : (p.wino == 1 ? "wino" : p.wino == 2 ? "wino4" : ""), p.O, p.K, p.M, p.S, d->KH);
     ProfScope prof(pname, 2.0 * macs_, 4.0 * (pix_in_ * cir_ + pix_out_ * cor_ + cir_ * cor_ * d->KH * d->KW), s);
-    if (p.wino) {
+    if (p.wino == 3) {
+        auto kern = P.relu_g ? wgrad_fast_kernel<4, 1, 1, 3, false, true, 3> : wgrad_fast_kernel<4, 1, 1, 3, false, false, 3>;
+        const size_t lds = (size_t)2 * WG_BKR * (128 + 96) * sizeof(float);
+        allow_big_lds(kern, lds);
+        hipLaunchKernelGGL(kern, dim3(4 * (P.O / 128) * p.S), dim3(256), lds, s, P);
+        e = check_launch("wgrad_fast_kernel<wino sw>");
+    } else if (p.wino) {
         auto kern = P.relu_x ? wgrad_fast_kernel<2, 2, 2, 2, true, false, 1> : wgrad_fast_kernel<2, 2, 2, 2, false, false, 1>;
         if (p.wino == 2)
             kern = P.relu_x ? wgrad_fast_kernel<2, 2, 2, 2, true, false, 2>
@@ -1051,7 +1095,7 @@ extern "C" int vq2_wgrad_job_init(const vq2_conv_desc *d, const void *ws, float 
     job->O = p.O; job->I = p.I; job->Or = sw ? cir : cor; job->Ir = sw ? cor : cir;
     job->swapped = p.swapped | (p.wino << 1); job->bias_splits = 0;
     job->taps = d->KH * d->KW; job->S = p.S;
-    job->n_units_w = p.wino ? (p.O * (p.wino == 1 ? 3 : 8) * p.I + 31) / 32 : (p.O * p.K + 31) / 32;
+    job->n_units_w = p.wino ? (p.O * (p.wino == 2 ? 8 : 3) * p.I + 31) / 32 : (p.O * p.K + 31) / 32;
     job->n_units_b = 0;
     if (db) {
         int taps, nslots;
