@@ -264,6 +264,42 @@ def test_winograd_exchanged_roles_weight_gradient_of_the_resblock_3x3(amd, shape
         close(db.double(), br.grad, rtol=0, atol=1e-5 * float(br.grad.abs().max()), what=tag + ".db%d" % relu_in)
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 64, 128, 64), (1, 4, 128, 40, 128), (3, 12, 64, 32, 64)])
+def test_winograd_subpixel_conv_transpose_forward_and_k4s2_data_gradient(amd, shape):
+    """ConvTranspose2d(k4,s2,p1) with >= 32 input channels, output channels in whole 64-tiles and input rows of whole
+    64-pixel segments: every output phase is a 2-tap filter along the row and runs as F(2,2) (wino_subpixel_kernel).
+    Forward with ReLU-in / bias / ReLU-out through channel slices, and the data gradient of the 4x4 stride-2 conv (the same
+    operation on dy) with its ReLU mask, against fp64."""
+    from vqvae2_amd import ops
+    dev = torch.device("cuda:0")
+    n, h, w, ci, co = shape                                   # input h x w, output 2h x 2w
+    tag = "spw_%dx%dx%d" % (h, w, ci)
+    wide_in = t(rng.normal(17, tag + ".in", (n, h, w, ci + 4))).to(dev)
+    x = wide_in[..., 4:4 + ci]
+    wide_out = torch.full((n, 2 * h, 2 * w, co + 8), 7.0, device=dev)
+    wt = t(rng.uniform(17, tag + ".w", (ci, co, 4, 4), -0.1, 0.1)).to(dev)      # IOHW
+    b = t(rng.uniform(17, tag + ".b", (co,), -1, 1)).to(dev)
+    tspec = ops.ConvSpec(True, ci, co, 4, 2, 1)
+    y, seen = _launched(amd, lambda: ops.conv_forward(tspec, x, wt, b, ops.VQ2_RELU_IN | ops.VQ2_RELU_OUT,
+                                                      out=wide_out[..., 4:4 + co]))
+    assert any(k.startswith("conv_wino_subpixel") for k in seen), seen
+    x64 = x.permute(0, 3, 1, 2).cpu().double()
+    ref = F.relu(F.conv_transpose2d(F.relu(x64), wt.cpu().double(), b.cpu().double(), stride=2, padding=1)).permute(0, 2, 3, 1)
+    close(y.double(), ref, rtol=0, atol=5e-6 * float(ref.abs().max()), what=tag + ".y")
+    assert float(wide_out[..., :4].min()) == 7.0 and float(wide_out[..., 4 + co:].max()) == 7.0
+    # data gradient of Conv2d(co -> ci, k4 s2 p1) whose input is the 2h x 2w tensor: dx = conv_transpose(dy)
+    spec = ops.ConvSpec(False, co, ci, 4, 2, 1)
+    wc = t(rng.uniform(17, tag + ".wc", (ci, co, 4, 4), -0.1, 0.1)).to(dev)      # OIHW of that conv: [ci][co]
+    xin = t(rng.normal(17, tag + ".xin", (n, 2 * h, 2 * w, co))).to(dev)
+    dy = t(rng.normal(17, tag + ".dy", (n, h, w, ci))).to(dev)
+    dx, seen = _launched(amd, lambda: ops.conv_dgrad(spec, (n, 2 * h, 2 * w, co), dy, wc, mask=xin))
+    assert any(k.startswith("conv_wino_subpixel") for k in seen), seen
+    xr = xin.permute(0, 3, 1, 2).cpu().double().clone().requires_grad_(True)
+    F.conv2d(F.relu(xr), wc.cpu().double(), None, stride=2, padding=1).backward(dy.permute(0, 3, 1, 2).cpu().double())
+    refg = xr.grad.permute(0, 2, 3, 1)
+    close(dx.double(), refg, rtol=0, atol=5e-6 * float(refg.abs().max()), what=tag + ".dx")
+
+
 def test_layout_conversion_generic_channels(amd):
     from vqvae2_amd import ops
     dev = torch.device("cuda:0")

@@ -46,10 +46,11 @@ __device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
 // Epilogue shared by the kernels of this file: lane (lane & 31) of a wave holds the first output pixel of its pair in
-// pix_lane (shared through ds_bpermute); vals(j, r, y0, y1) yields the two outputs of accumulator row r of column block j.
+// pix_lane (shared through ds_bpermute), the second one is dpix further; vals(j, r, y0, y1) yields the two outputs of
+// accumulator row r of column block j.
 // Then exactly the direct kernel's epilogue (vq2_conv.hip): bias, ReLU mask, residual, ReLU, strided store.
 template <int NT, class F>
-__device__ __forceinline__ void store_pairs(const ConvGemmParams &P, int co0, int lane, int pix_lane, F vals) {
+__device__ __forceinline__ void store_pairs(const ConvGemmParams &P, int co0, int lane, int pix_lane, F vals, int dpix = 1) {
     const int ybytes = P.N * P.Hy * P.Wy * 4;
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(P.y, 0, ybytes * P.ldy, RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rmk =
@@ -76,7 +77,7 @@ __device__ __forceinline__ void store_pairs(const ConvGemmParams &P, int co0, in
                 const int rr = rowq + (r & 3) + 8 * (r >> 2);
                 const int p0 = __shfl(pix_lane, rr, 64);
                 pix[2 * q] = p0;
-                pix[2 * q + 1] = p0 + 1;
+                pix[2 * q + 1] = p0 + dpix;
                 vals(j, r, val[2 * q], val[2 * q + 1]);
             }
             if (has_mask) {
@@ -443,6 +444,172 @@ static int launch_k4s2(const ConvGemmParams &P, hipStream_t s) {
     return check_launch("wino_k4s2_kernel");
 }
 
+// ====================================================================== sub-pixel form of ConvTranspose2d(k4,s2,p1)
+// (forward, and the data gradient of a 4x4 stride-2 conv.)  Output phase (ph, pw) is a 2x2 stride-1 conv over the input,
+//     y[2h+ph][2w+pw] = sum_{a,b} x[h+a-1+ph][w+b-1+pw] g[ph][pw][a][b]      (panel [phase][co][(a, b, ci)]),
+// i.e. along a row a 2-tap filter: F(2,2) over pairs of same-phase outputs (input columns 2t, 2t+1), three products instead
+// of four.  Workgroup = 4 input rows x 32 pairs x 64 output channels of ONE phase (blockIdx -> phase fastest: the four
+// phases of a tile run next to each other on one XCD and share the patch lines in its L2); wave = one row, 32 pairs x 64
+// channels; the 5 x 65 patch of an 8-channel block serves both kernel rows a.
+namespace sp2 {
+constexpr int BN2 = 64;
+constexpr int TR = 4, NPC = 65, NPX = (TR + 1) * NPC;    // patch rows x entries (2t + {0,1,2}, t < 32)
+constexpr int A_FLOATS = (NPX + 1) * LDK;
+constexpr int A_ITEMS = NPX * 2;
+constexpr int A_LD = (A_ITEMS + 255) / 256;
+constexpr int B_FLOATS2 = 3 * BN2 * LDK;
+constexpr size_t LDS_BYTES = (size_t)2 * (A_FLOATS + B_FLOATS2) * sizeof(float);
+}  // namespace sp2
+
+template <bool RELU_IN>
+__global__ __launch_bounds__(256, 2) void wino_subpixel_kernel(const ConvGemmParams P) {
+    constexpr int NT = 2;
+    using namespace sp2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                    // [2][A_FLOATS]
+    float *Bs = smem + 2 * A_FLOATS;     // [2][3][BN2][LDK]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntn = P.Co / BN2, tw = P.W / 64, th = P.H / TR;
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int phase = vid & 3;
+    const int ph = phase >> 1, pw = phase & 1;
+    const int v2 = vid >> 2;
+    const int n0 = (v2 % ntn) * BN2;
+    const int sp = v2 / ntn;
+    const int wb = sp % tw, hb = (sp / tw) % th, n = sp / (tw * th);
+    const int h0 = hb * TR, w0 = wb * 64;
+    const int row0 = h0 - 1 + ph, col0 = w0 - 1 + pw;       // input pixel of patch entry (0, 0)
+
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x), 0, P.N * P.H * P.W * P.ldx * 4, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(P.w + (size_t)phase * P.Co * P.K), 0, P.Co * P.K * 4, RSRC_FLAGS);
+
+    int a_off[A_LD], a_dst[A_LD];
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+        const int it = tid + 256 * j;
+        const bool ok = it < A_ITEMS;
+        const int px = ok ? (it >> 1) : 0, q = it & 1;
+        const int r = px / NPC, e = px - r * NPC;
+        const int row = row0 + r, col = col0 + e;
+        const bool in = ok && (unsigned)row < (unsigned)P.H && (unsigned)col < (unsigned)P.W;
+        a_off[j] = in ? (((n * P.H + row) * P.W + col) * P.ldx + 4 * q) * 4 : (int)0x80000000;
+        a_dst[j] = (ok ? px : NPX) * LDK + 4 * q;
+    }
+    const bool role_b = tid < 2 * BN2;
+    const int bco = (tid & (2 * BN2 - 1)) >> 1, bq = tid & 1;
+    const int b_off = ((n0 + bco) * P.K + 4 * bq) * 4;
+    const int b_dst = bco * LDK + 4 * bq;
+    const int ci4 = P.Ci * 4;
+
+    u32x4 ra[A_LD], rb[2];
+    auto load_b = [&](int a, int cb) {
+        const int kb = (a * 2 * P.Ci + cb) * 4;       // taps (a, 0) and (a, 1)
+        rb[0] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_off + kb, 0, 0);
+        rb[1] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_off + kb + ci4, 0, 0);
+    };
+    auto store_b = [&](float *b) {
+        const float4 ga = as_f4(rb[0]), gb = as_f4(rb[1]);
+        *reinterpret_cast<float4 *>(b + 0 * BN2 * LDK + b_dst) = ga;
+        *reinterpret_cast<float4 *>(b + 1 * BN2 * LDK + b_dst) = add4(ga, gb);
+        *reinterpret_cast<float4 *>(b + 2 * BN2 * LDK + b_dst) = gb;
+    };
+    auto load_a = [&](int cb) {
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, a_off[j] + cb * 4, 0, 0);
+    };
+    auto store_a = [&](float *a) {
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            const float4 v = as_f4(ra[j]);
+            *reinterpret_cast<float4 *>(a + a_dst[j]) = RELU_IN ? relu4(v) : v;
+        }
+    };
+
+    f32x16 acc[3][NT];
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[v][j][r] = 0.f;
+
+    const int frag_row = lane & 31, frag_k = 4 * (lane >> 5);
+    const int lane_a = (wave * NPC + 2 * frag_row) * LDK + frag_k;      // input row `wave` of the tile, pair frag_row
+    const int lane_b = frag_row * LDK + frag_k;
+
+    auto compute = [&](const float *a, const float *b, int arow) {
+        const float *ap = a + lane_a + arow * NPC * LDK;
+        const float4 d0 = *reinterpret_cast<const float4 *>(ap);
+        const float4 d1 = *reinterpret_cast<const float4 *>(ap + LDK);
+        const float4 d2 = *reinterpret_cast<const float4 *>(ap + 2 * LDK);
+        float4 fb[3][NT];
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[v][j] = *reinterpret_cast<const float4 *>(b + (v * BN2 + j * 32) * LDK + lane_b);
+        float4 fv[3];
+        fv[0] = sub4(d0, d1);
+        fv[1] = d1;
+        fv[2] = sub4(d1, d2);
+#define VQ2_WINO_STEP(C)                                                                                          \
+    _Pragma("unroll") for (int v = 0; v < 3; ++v) _Pragma("unroll") for (int j = 0; j < NT; ++j)                  \
+        acc[v][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[v].C, fb[v][j].C, acc[v][j], 0, 0, 0);
+        VQ2_WINO_STEP(x) VQ2_WINO_STEP(y) VQ2_WINO_STEP(z) VQ2_WINO_STEP(w)
+#undef VQ2_WINO_STEP
+    };
+
+    const int NCB = P.Ci / BK;
+    load_a(0);
+    load_b(0, 0);
+    store_a(As);
+    if (role_b) store_b(Bs);
+    __syncthreads();
+
+    int c = 0;
+    for (int cbi = 0; cbi < NCB; ++cbi) {
+        const int cbn = (cbi + 1 < NCB) ? (cbi + 1) * BK : cbi * BK;   // (the last block re-loads itself into the idle buffer)
+        const float *a_cur = As + (cbi & 1) * A_FLOATS;
+        float *a_nxt = As + ((cbi + 1) & 1) * A_FLOATS;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            if (a == 0) {
+                load_b(1, cbi * BK);
+                load_a(cbn);                                        // behind the weight loads, stored a chunk later
+            } else {
+                load_b(0, cbn);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            compute(a_cur, Bs + (c & 1) * B_FLOATS2, a);
+            __builtin_amdgcn_sched_barrier(0);
+            if (role_b) store_b(Bs + ((c + 1) & 1) * B_FLOATS2);
+            if (a == 1) store_a(a_nxt);
+            __syncthreads();
+            ++c;
+        }
+    }
+
+    const int pix_lane = ((n * P.Hy + 2 * (h0 + wave) + ph) * P.Wy + 2 * (w0 + 2 * frag_row) + pw);
+    store_pairs<NT>(P, n0, lane, pix_lane, [&](int j, int r, float &y0, float &y1) {
+        const float m1 = acc[0][j][r], m2 = acc[1][j][r], m3 = acc[2][j][r];
+        y0 = m1 + m2;
+        y1 = m2 - m3;
+    }, 2);
+}
+
+static int launch_subpixel2(const ConvGemmParams &P, hipStream_t s) {
+    auto kern = P.relu_in ? wino_subpixel_kernel<true> : wino_subpixel_kernel<false>;
+    allow_big_lds(kern, sp2::LDS_BYTES);
+    const unsigned nwg = (unsigned)(4 * P.N * (P.H / sp2::TR) * (P.W / 64) * (P.Co / sp2::BN2));
+    const char *name = "conv_wino_subpixel";
+    if (prof_enabled()) name = prof_label("conv_wino_subpixel<4x64>|M=%d,N=%d,K=%d,ph4", P.M, P.Co, P.K);
+    ProfScope prof(name, P.flops, P.bytes, s, true);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), sp2::LDS_BYTES, s, P);
+    return check_launch("wino_subpixel_kernel");
+}
+
 template <int TPW, int NT>
 static int launch(const ConvGemmParams &P, hipStream_t s) {
     using G = Geo<TPW, NT>;
@@ -469,6 +636,12 @@ static int tune(const char *name, int dflt) {
 bool wino3_ok(const ConvGemmParams &P) {
     static const int on = wino::tune("VQ2_WINO", 1), on4 = wino::tune("VQ2_WINO_K4", 1);
     const long gib = 1L << 30;
+    static const int onsp = wino::tune("VQ2_WINO_SP", 1);
+    if (P.phases == 4)   // sub-pixel conv-transpose: F(2,2) per output phase
+        return onsp && P.KH == 2 && P.KW == 2 && P.K == 4 * P.Ci && P.Hy == 2 * P.H && P.Wy == 2 * P.W && P.W % 64 == 0 &&
+               P.H % 4 == 0 && P.Ci % wino::BK == 0 && P.Ci >= 32 && P.Co % 64 == 0 && P.ldx % 4 == 0 &&
+               (long)P.N * P.H * P.W * P.ldx * 4 < gib && (long)P.N * P.Hy * P.Wy * P.ldy * 4 < gib &&
+               (long)P.N * P.Hy * P.Wy * (P.ldm > P.ldr ? P.ldm : P.ldr) * 4 < gib && (long)4 * P.Co * P.K * 4 < gib;
     if (on4 && P.KH == 4 && P.KW == 4 && P.stride == 2 && P.pad_h == 1 && P.pad_w == 1 && P.phases == 1)   // F(2,2) by parity
         return 2 * P.Ho == P.H && 2 * P.Wo == P.W && P.Hy == P.Ho && P.Wy == P.Wo && P.Wo % 64 == 0 && P.Ho % 2 == 0 &&
                P.Ci % wino::BK == 0 && P.Ci >= 32 && P.Co % wino::BN == 0 && P.ldx % 4 == 0 &&
@@ -484,6 +657,7 @@ bool wino3_ok(const ConvGemmParams &P) {
 // (NT = 1 -- eight waves of 32 pairs x 32 channels, four per SIMD at <= 128 registers -- measured no faster than NT = 2
 //  and does not fit its register budget once the staging loads are held across the MFMA phase; not instantiated.)
 int launch_wino3(const ConvGemmParams &P, hipStream_t s) {
+    if (P.phases == 4) return wino::launch_subpixel2(P, s);
     if (P.KH == 4) return wino::launch_k4s2(P, s);
     return wino::launch<32, 2>(P, s);
 }
