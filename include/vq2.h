@@ -168,7 +168,10 @@ typedef struct vq2_wgrad_job {
     float *db;            /* bias gradient destination or NULL                  */
     int64_t unit_offset;  /* start of this job in the batched unit space        */
     int32_t O, I, Or, Ir, taps, S, n_units_w, n_units_b;
-    int32_t swapped;      /* slab is [ci][flipped tap][co] (roles of x and dy exchanged)            */
+    int32_t swapped;      /* bit 0: slab is [ci][flipped tap][co] (roles of x and dy exchanged);
+                             bits 1-2: Winograd slab layout written by vq2_conv_wgrad_partial (0 none, 1 F(2,3) over
+                             column pairs, 2 F(2,2) by column parity, 3 F(2,3) with exchanged roles) -- filled by
+                             vq2_wgrad_job_init, interpreted by vq2_wgrad_reduce_batched                        */
     int32_t bias_splits;  /* > 0: bias partials are [bias_splits][I] (taken from the gathered dy
                              operand: exchanged roles, conv-transpose); 0: [S][O]                  */
 } vq2_wgrad_job;

@@ -15,7 +15,10 @@ rnd = sys.argv[1]
 src = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
 # bench.py's kernel-family label -> the template instances behind it in the rocprofv3 kernel names
 FAMILIES = {"conv_gemm<128x128x16>": r"conv_gemm_fast_kernel<2, 2, 2, 2, 16,",
-            "conv_gemm<128x128x32>": r"conv_gemm_fast_kernel<2, 2, 2, 2, 32,"}
+            "conv_gemm<128x128x32>": r"conv_gemm_fast_kernel<2, 2, 2, 2, 32,",
+            "conv_wino3<2x64,nt2>": r"(vq2::)?(wino::)?wino3_kernel<32, 2,",
+            "conv_wino_k4s2<2x64>": r"(vq2::)?(wino::)?wino_k4s2_kernel<",
+            "conv_wino_subpixel<4x64>": r"(vq2::)?(wino::)?wino_subpixel_kernel<"}
 BATCH = {"c2": 32, "c4": 32, "c5": 8}
 out = {}
 for w in ("c2", "c4", "c5"):
