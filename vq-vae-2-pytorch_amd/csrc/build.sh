@@ -9,8 +9,8 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function"
 mkdir -p "$OBJ"
 pids=()
-for f in vq2_conv vq2_wino vq2_wgrad vq2_vq vq2_elem vq2_resblock vq2_norm; do
-  if [ ! -f "$OBJ/$f.o" ] || [ "$HERE/$f.hip" -nt "$OBJ/$f.o" ] || [ "$HERE/vq2_common.h" -nt "$OBJ/$f.o" ] || [ "$HERE/vq2_conv.h" -nt "$OBJ/$f.o" ] || [ "$HERE/../../include/vq2.h" -nt "$OBJ/$f.o" ]; then
+for f in vq2_conv vq2_wino vq2_rbwino vq2_wgrad vq2_vq vq2_elem vq2_resblock vq2_norm; do
+  if [ ! -f "$OBJ/$f.o" ] || [ "$HERE/$f.hip" -nt "$OBJ/$f.o" ] || [ "$HERE/vq2_common.h" -nt "$OBJ/$f.o" ] || [ "$HERE/vq2_conv.h" -nt "$OBJ/$f.o" ] || [ "$HERE/vq2_rbwino.h" -nt "$OBJ/$f.o" ] || [ "$HERE/../../include/vq2.h" -nt "$OBJ/$f.o" ]; then
     # the compiler's per-kernel resource report (VGPRs, spills, scratch, occupancy) is kept next to the object:
     # tests/test_host_cpu.py::test_hot_kernels_do_not_spill reads it (a spilled register in a conv tile cost 3 % of
     # the step in round 2 and no functional test could see it)

@@ -16,6 +16,7 @@
 // Every tile is computed the same way whatever the batch size: results do not depend on N (an 8-wave
 // variant that split the depth between two wave groups was measured equal at 32x32 and dropped).
 #include "vq2_common.h"
+#include "vq2_rbwino.h"
 #include <stdlib.h>
 
 namespace vq2 {
@@ -895,6 +896,18 @@ extern "C" int vq2_resblock_fwd(int32_t N, int32_t H, int32_t W, int32_t C, int3
     const double npix = (double)N * H * W;
     const int ldmax = ldx > ldy ? ldx : ldy;
     VQ2_REQUIRE(npix * ldmax * 4.0 < (double)rb::OOB, "resblock_fwd: tensors must be smaller than %d bytes", rb::OOB);
+    {   // rows of whole 64-pixel segments: the 3x3 in the Winograd domain (vq2_rbwino.hip)
+        RbwFwdParams Q{};
+        Q.x = x; Q.w1 = w1p; Q.b1 = b1; Q.w2 = w2p; Q.b2 = b2; Q.r = r; Q.y = y;
+        Q.N = N; Q.H = H; Q.W = W; Q.ldx = ldx; Q.ldr = ldr; Q.ldy = ldy; Q.relu_out = (flags & VQ2_RELU_OUT) != 0;
+        if (ldr >= Cm && rbw_fwd_ok(Q) && !g_rb_stamps_fwd) {
+            hipStream_t s = to_stream(stream);
+            const char *name = "resblock_fwd_wino";
+            if (prof_enabled()) name = prof_label("resblock_fwd_wino|M=%d,C=%d,Cm=%d", N * H * W, C, Cm);
+            ProfScope prof(name, 2.0 * npix * (9.0 * C * Cm + (double)Cm * C), 4.0 * npix * (2.0 * C + Cm), s);
+            return launch_rbw_fwd(Q, s);
+        }
+    }
     ResFwdParams P{};
     P.x = x; P.w1 = w1p; P.b1 = b1; P.w2 = w2p; P.b2 = b2; P.r = r; P.y = y;
     P.N = N; P.H = H; P.W = W; P.ldx = ldx; P.ldr = ldr; P.ldy = ldy;
