@@ -36,5 +36,6 @@ for n, hw in ((32, 32), (64, 32), (128, 32), (8, 64), (16, 64), (32, 64), (64, 6
         if name.startswith("resblock"):
             row[name.split("|")[0]] = (float(ms) * 1e3 / int(cnt), float(fl) / float(ms) / 1e9)
     wgs = n * (hw // 8) * (hw // 16)
+    # (workgroup count of the direct 8 x 16 tile; resblock_fwd_wino uses 4 x 64 tiles: half as many)
     print(f"N={n:3d} {hw}x{hw} workgroups={wgs:5d} ({wgs / 256:.1f}/CU): " +
           "  ".join(f"{k} {v[0]:6.1f} us {v[1]:6.1f} TF" for k, v in sorted(row.items())), flush=True)
