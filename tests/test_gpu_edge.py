@@ -121,10 +121,12 @@ def _launched(amd, fn):
     return out, [ln.split()[0] for ln in buf.value.decode().splitlines()]
 
 
-@pytest.mark.parametrize("shape", [(2, 6, 64, 64, 128), (1, 4, 128, 72, 256), (3, 2, 64, 128, 128), (2, 6, 128, 128, 256)])
+@pytest.mark.parametrize("shape", [(2, 6, 64, 64, 128), (1, 4, 128, 72, 256), (3, 2, 64, 128, 128), (2, 6, 128, 128, 256),
+                                   (2, 8, 32, 64, 128), (1, 4, 32, 128, 64), (2, 4, 64, 64, 64), (33, 32, 32, 64, 128)])
 def test_winograd_rows_conv_forward_and_data_gradient(amd, shape):
-    """3x3 stride-1 convolutions with >= 64 input channels, whole 128-channel output tiles and rows of whole 64-pixel
-    segments run as F(2,3) Winograd along the rows (csrc/vq2_wino.hip): forward with ReLU-in / bias / residual / ReLU-out
+    """3x3 stride-1 convolutions with >= 64 input channels, whole 64-channel output tiles and rows of whole 64-pixel segments
+    (or 32-pixel ones, H % 4 == 0: the 32x32 level; the last case is a launch large enough for 128-wide tiles there) run as
+    F(2,3) Winograd along the rows (csrc/vq2_wino.hip): forward with ReLU-in / bias / residual / ReLU-out
     through channel slices, data gradient with the ReLU mask and the skip gradient, against fp64 torch on the CPU.  The
     image border (zero padding on all four sides) and the seams between 64-pixel segments are part of every case."""
     from vqvae2_amd import ops
@@ -151,8 +153,8 @@ def test_winograd_rows_conv_forward_and_data_gradient(amd, shape):
     assert any(k.startswith("conv_wino3") for k in seen), seen
     ref2 = F.conv2d(x64, wt.cpu().double(), None, padding=1).permute(0, 2, 3, 1)
     close(y2.double(), ref2, rtol=0, atol=5e-6 * float(ref2.abs().max()), what=tag + ".y2")
-    # data gradient (the same kernel on the flipped panel) needs whole 128-channel tiles of the INPUT channel count
-    if ci % 128 == 0:
+    # data gradient (the same kernel on the flipped panel) needs whole 64-channel tiles of the INPUT channel count
+    if ci % 64 == 0:
         dy = t(rng.normal(9, tag + ".dy", (n, h, w, co))).to(dev)
         dx_wide = torch.zeros((n, h, w, ci + 8), device=dev)
         dx, seen = _launched(amd, lambda: ops.conv_dgrad(spec, (n, h, w, ci), dy, wt, mask=x, residual=wide_in[..., 0:ci],
@@ -163,8 +165,8 @@ def test_winograd_rows_conv_forward_and_data_gradient(amd, shape):
         refg = xr.grad.permute(0, 2, 3, 1) + wide_in[..., 0:ci].cpu().double()
         close(dx.double(), refg, rtol=0, atol=5e-6 * float(refg.abs().max()), what=tag + ".dx")
         # weight and bias gradient: the same transform on the reduction side (wgrad_fast_kernel<..., WINO>, whole 128-channel
-        # tiles on both sides), with and without the fused ReLU on x, through channel slices
-        if co % 128 == 0:
+        # tiles on both sides, rows of whole 64-pixel segments), with and without the fused ReLU on x, through channel slices
+        if co % 128 == 0 and ci % 128 == 0 and w % 64 == 0:
             wr = wt.cpu().double().clone().requires_grad_(True)
             br = b.cpu().double().clone().requires_grad_(True)
             for relu_in in (True, False):

@@ -32,14 +32,19 @@ constexpr int BN = 128;            // output channels per workgroup
 constexpr int BK = 8, LDK = BK + 4;   // 48-byte LDS rows: conflict-free ds_read_b128 (vq2_conv.hip)
 constexpr int B_FLOATS = 4 * BN * LDK;
 
-template <int TPW, int NT>
+// TPW: pairs per tile row (32: rows of whole 64-pixel segments, 2-row tiles; 16: 32-pixel segments, 4-row tiles -- a wave's
+// 32 pairs are then two rows).  (NT, BNT): a wave owns 32 pairs x 32*NT channels of a BNT-channel tile -- (2, 128), or (1, 64)
+// for layers with 64-channel outputs and for the 32x32 level, where 128-wide tiles would leave one workgroup per CU.
+template <int TPW, int NT, int BNT = BN>
 struct Geo {
-    static constexpr int NWN = 4 / NT, NTHR = 128 * NWN;
+    static constexpr int NWN = BNT / (32 * NT), NTHR = 256;
+    static_assert(NWN == 2, "two waves along the pairs, two along the channels");
     static constexpr int TR = TP / TPW, PR = TR + 2, PW = 2 * TPW + 2, NPX = PR * PW;
     static constexpr int A_FLOATS = (NPX + 1) * LDK;          // + one dump row for the items past the patch
     static constexpr int A_ITEMS = NPX * 2;                    // (pixel, 4-channel quad)
     static constexpr int A_LD = (A_ITEMS + NTHR - 1) / NTHR;
-    static constexpr size_t LDS_BYTES = (size_t)2 * (A_FLOATS + B_FLOATS) * sizeof(float);
+    static constexpr int B_FLOATS_T = 4 * BNT * LDK;
+    static constexpr size_t LDS_BYTES = (size_t)2 * (A_FLOATS + B_FLOATS_T) * sizeof(float);
 };
 
 __device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
@@ -104,19 +109,20 @@ __device__ __forceinline__ void store_pairs(const ConvGemmParams &P, int co0, in
     }
 }
 
-template <int TPW, int NT, bool RELU_IN>
-__global__ __launch_bounds__(128 * (4 / NT), NT == 1 ? 4 : 2) void wino3_kernel(const ConvGemmParams P) {
-    using G = Geo<TPW, NT>;
+template <int TPW, int NT, int BNT, bool RELU_IN>
+__global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void wino3_kernel(const ConvGemmParams P) {
+    using G = Geo<TPW, NT, BNT>;
+    constexpr int B_FLOATS_T = G::B_FLOATS_T;
     constexpr int NWN = G::NWN, NTHR = G::NTHR, PW = G::PW, NPX = G::NPX, A_FLOATS = G::A_FLOATS, A_LD = G::A_LD;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                    // [2][A_FLOATS]   raw patch of one 8-channel block
-    float *Bs = smem + 2 * A_FLOATS;     // [2][4][BN][LDK] transformed taps of one (kernel row, channel block)
+    float *Bs = smem + 2 * A_FLOATS;     // [2][4][BNT][LDK] transformed taps of one (kernel row, channel block)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / NWN, wn = wave % NWN;
-    const int ntn = P.Co / BN, tw = P.W / (2 * TPW), th = P.H / G::TR;
+    const int ntn = P.Co / BNT, tw = P.W / (2 * TPW), th = P.H / G::TR;
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
-    const int n0 = (vid % ntn) * BN;
+    const int n0 = (vid % ntn) * BNT;
     const int sp = vid / ntn;
     const int wb = sp % tw, hb = (sp / tw) % th, n = sp / (tw * th);
     const int h0 = hb * G::TR, w0 = wb * 2 * TPW;
@@ -140,9 +146,9 @@ __global__ __launch_bounds__(128 * (4 / NT), NT == 1 ? 4 : 2) void wino3_kernel(
         a_off[j] = in ? (((n * P.H + row) * P.W + col) * P.ldx + 4 * q) * 4 : (int)0x80000000;
         a_dst[j] = (ok ? px : NPX) * LDK + 4 * q;
     }
-    // weight items (co, quad): the first 256 threads
-    const bool role_b = (NTHR == 256) || tid < 256;
-    const int bco = (tid & 255) >> 1, bq = tid & 1;
+    // weight items (co, quad): the first 2 * BNT threads
+    const bool role_b = tid < 2 * BNT;
+    const int bco = (tid & (2 * BNT - 1)) >> 1, bq = tid & 1;
     const int b_off = ((n0 + bco) * P.K + 4 * bq) * 4;
     const int b_dst = bco * LDK + 4 * bq;
     const int ci4 = P.Ci * 4;
@@ -156,10 +162,10 @@ __global__ __launch_bounds__(128 * (4 / NT), NT == 1 ? 4 : 2) void wino3_kernel(
     auto store_b = [&](float *b) {
         const float4 g0 = as_f4(rb[0]), g1 = as_f4(rb[1]), g2 = as_f4(rb[2]);
         const float4 t = add4(g0, g2);
-        *reinterpret_cast<float4 *>(b + 0 * BN * LDK + b_dst) = g0;
-        *reinterpret_cast<float4 *>(b + 1 * BN * LDK + b_dst) = VQ2_WINO_EXP == 4 ? g1 : add4(t, g1);
-        *reinterpret_cast<float4 *>(b + 2 * BN * LDK + b_dst) = VQ2_WINO_EXP == 4 ? g1 : sub4(t, g1);
-        *reinterpret_cast<float4 *>(b + 3 * BN * LDK + b_dst) = g2;
+        *reinterpret_cast<float4 *>(b + 0 * BNT * LDK + b_dst) = g0;
+        *reinterpret_cast<float4 *>(b + 1 * BNT * LDK + b_dst) = VQ2_WINO_EXP == 4 ? g1 : add4(t, g1);
+        *reinterpret_cast<float4 *>(b + 2 * BNT * LDK + b_dst) = VQ2_WINO_EXP == 4 ? g1 : sub4(t, g1);
+        *reinterpret_cast<float4 *>(b + 3 * BNT * LDK + b_dst) = g2;
     };
     auto store_a = [&](float *a, int j) {
         const float4 v = as_f4(ra[j]);
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(128 * (4 / NT), NT == 1 ? 4 : 2) void wino3_kernel(
 #pragma unroll
         for (int v = 0; v < 4; ++v)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) fb[v][j] = *reinterpret_cast<const float4 *>(b + (v * BN + j * 32) * LDK + lane_b);
+            for (int j = 0; j < NT; ++j) fb[v][j] = *reinterpret_cast<const float4 *>(b + (v * BNT + j * 32) * LDK + lane_b);
         float4 fv[4];
         if (VQ2_WINO_EXP == 3) { fv[0] = d0; fv[1] = d1; fv[2] = d2; fv[3] = d3; } else {
         fv[0] = sub4(d0, d2);
@@ -237,10 +243,10 @@ __global__ __launch_bounds__(128 * (4 / NT), NT == 1 ? 4 : 2) void wino3_kernel(
                 }
             }
             __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks the loads to just before their stores)
-            compute(a_cur, Bs + (c & 1) * B_FLOATS, kh);
+            compute(a_cur, Bs + (c & 1) * B_FLOATS_T, kh);
             __builtin_amdgcn_sched_barrier(0);
             if (VQ2_WINO_EXP != 2) {
-                if (role_b) store_b(Bs + ((c + 1) & 1) * B_FLOATS);
+                if (role_b) store_b(Bs + ((c + 1) & 1) * B_FLOATS_T);
                 if (kh == 1) {
 #pragma unroll
                     for (int j = 0; j < A_LD; ++j) store_a(a_nxt, j);
@@ -615,12 +621,12 @@ static int launch_subpixel2(const ConvGemmParams &P, hipStream_t s) {
     return check_launch("wino_subpixel_kernel");
 }
 
-template <int TPW, int NT>
+template <int TPW, int NT, int BNT>
 static int launch(const ConvGemmParams &P, hipStream_t s) {
-    using G = Geo<TPW, NT>;
-    auto kern = P.relu_in ? wino3_kernel<TPW, NT, true> : wino3_kernel<TPW, NT, false>;
+    using G = Geo<TPW, NT, BNT>;
+    auto kern = P.relu_in ? wino3_kernel<TPW, NT, BNT, true> : wino3_kernel<TPW, NT, BNT, false>;
     allow_big_lds(kern, G::LDS_BYTES);
-    const unsigned nwg = (unsigned)(P.N * (P.H / G::TR) * (P.W / (2 * TPW)) * (P.Co / BN));
+    const unsigned nwg = (unsigned)(P.N * (P.H / G::TR) * (P.W / (2 * TPW)) * (P.Co / BNT));
     const char *name = "conv_wino";
     if (prof_enabled()) name = prof_label("conv_wino3<%dx%d,nt%d>|M=%d,N=%d,K=%d", G::TR, 2 * TPW, NT, P.M, P.Co, P.K);
     ProfScope prof(name, P.flops, P.bytes, s, true);
@@ -635,9 +641,9 @@ static int tune(const char *name, int dflt) {
 
 }  // namespace wino
 
-// Shapes the Winograd kernel takes: 3x3, stride 1, pad 1, output the size of the input, whole 128-channel output tiles,
-// 8-channel input blocks, rows of whole 64-pixel segments, tensors below 1 GiB (32-bit offsets with an additive
-// out-of-range penalty).
+// Shapes the Winograd kernels take: 3x3, stride 1, pad 1, output the size of the input, whole 64-channel output tiles,
+// 8-channel input blocks (at least 64 channels), rows of whole 64-pixel segments (or 32-pixel ones with H % 4 == 0), tensors
+// below 1 GiB (32-bit offsets with an additive out-of-range penalty); likewise the 4x4 stride-2 and sub-pixel forms.
 bool wino3_ok(const ConvGemmParams &P) {
     static const int on = wino::tune("VQ2_WINO", 1), on4 = wino::tune("VQ2_WINO_K4", 1);
     const long gib = 1L << 30;
@@ -652,19 +658,23 @@ bool wino3_ok(const ConvGemmParams &P) {
                P.Ci % wino::BK == 0 && P.Ci >= 32 && P.Co % wino::BN == 0 && P.ldx % 4 == 0 &&
                (long)P.N * P.H * P.W * P.ldx * 4 < gib && (long)P.N * P.Ho * P.Wo * P.ldy * 4 < gib &&
                (long)P.N * P.Ho * P.Wo * (P.ldm > P.ldr ? P.ldm : P.ldr) * 4 < gib && (long)P.Co * P.K * 4 < gib;
+    const bool rows64 = P.W % 64 == 0 && P.H % 2 == 0, rows32 = P.W % 32 == 0 && P.H % 4 == 0;
     return on && P.KH == 3 && P.KW == 3 && P.stride == 1 && P.pad_h == 1 && P.pad_w == 1 && P.phases == 1 &&
            P.Ho == P.H && P.Wo == P.W && P.Hy == P.H && P.Wy == P.W && P.Ci % wino::BK == 0 && P.Ci >= 64 &&
-           P.Co % wino::BN == 0 && P.W % 64 == 0 && P.H % 2 == 0 && P.ldx % 4 == 0 &&
+           P.Co % 64 == 0 && (rows64 || rows32) && P.ldx % 4 == 0 &&
            (long)P.N * P.H * P.W * P.ldx * 4 < gib && (long)P.N * P.H * P.W * P.ldy * 4 < gib &&
            (long)P.N * P.H * P.W * (P.ldm > P.ldr ? P.ldm : P.ldr) * 4 < gib && (long)P.Co * P.K * 4 < gib;
 }
 
-// (NT = 1 -- eight waves of 32 pairs x 32 channels, four per SIMD at <= 128 registers -- measured no faster than NT = 2
-//  and does not fit its register budget once the staging loads are held across the MFMA phase; not instantiated.)
 int launch_wino3(const ConvGemmParams &P, hipStream_t s) {
     if (P.phases == 4) return wino::launch_subpixel2(P, s);
     if (P.KH == 4) return wino::launch_k4s2(P, s);
-    return wino::launch<32, 2>(P, s);
+    // 128-channel tiles where they still give every CU two workgroups; 64-channel tiles otherwise (64-channel outputs, the
+    // 32x32 level)
+    const long wgs128 = (long)P.N * P.H * P.W / 128 * (P.Co / 128);
+    const bool wide = P.Co % 128 == 0 && wgs128 >= 400;
+    if (P.W % 64 == 0 && P.H % 2 == 0) return wide ? wino::launch<32, 2, 128>(P, s) : wino::launch<32, 1, 64>(P, s);
+    return wide ? wino::launch<16, 2, 128>(P, s) : wino::launch<16, 1, 64>(P, s);
 }
 
 }  // namespace vq2
