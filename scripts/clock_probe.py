@@ -1,4 +1,5 @@
-"""In-kernel clock of the dominant conv instantiation (four-per-CU 128x128x16 tile, 3x3 128->128 at 64x64, batch 32):
+"""In-kernel clock of the dominant conv instantiation (the F(2,3) Winograd kernel, or with VQ2_WINO=0 the direct four-per-CU
+128x128x16 tile; 3x3 128->128 at 64x64, batch 32):
 lifetime of four workgroups in shader cycles (s_memtime) and in 10 ns ticks (s_memrealtime), after two seconds of
 back-to-back launches (MI355X_MICROARCH.md, DVFS give-back item 6).   VQ2_CLOCKPROBE=1 python scripts/clock_probe.py"""
 import ctypes as C, os, sys, time, torch
@@ -30,6 +31,7 @@ for slot, r in enumerate(buf.cpu().view(4, 4).tolist()):
     cyc, ticks, mfmas = r[0], r[1], r[2]
     if not ticks: continue
     clk = cyc / ticks * 0.1
+    res = 4 if os.environ.get("VQ2_WINO") == "0" else 2     # resident waves per SIMD (workgroups per CU)
     print(f"workgroup {8 + 256 * slot}: {cyc} cycles in {ticks * 10} ns -> {clk:.2f} GHz; {mfmas} MFMAs per wave x 64 cycles = "
-          f"{mfmas * 64} pipe cycles; with 4 waves per SIMD resident the pipe needs {4 * mfmas * 64} cycles per round of tiles -> "
-          f"utilisation {4 * mfmas * 64 / cyc:.2f}; fp32 MFMA peak at this clock {256 * 4 * 64 * clk / 1e3:.0f} TFLOP/s")
+          f"{mfmas * 64} pipe cycles; with {res} waves per SIMD resident the pipe needs {res * mfmas * 64} cycles per round of tiles -> "
+          f"utilisation {res * mfmas * 64 / cyc:.2f}; fp32 MFMA peak at this clock {256 * 4 * 64 * clk / 1e3:.0f} TFLOP/s")

@@ -1100,7 +1100,11 @@ static int run_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
                          (long)P.Co * P.K * P.phases < lim;
     static const int c4k = tune("VQ2_C4", 1);
     if (c4k && fast_ok && !legacy_stamps() && conv_c4_ok(P)) return launch_conv_c4(P, s);
-    if (fast_ok && !legacy_stamps() && wino3_ok(P)) return launch_wino3(P, s);   // vq2_wino.hip
+    if (fast_ok && !legacy_stamps() && wino3_ok(P)) {   // vq2_wino.hip
+        ConvGemmParams Q = P;
+        Q.stamps = g_stamps;        // (non-null only under vq2_debug_set_stamps + VQ2_CLOCKPROBE=1: the clock-probe instantiation)
+        return launch_wino3(Q, s);
+    }
     static const int subpix = tune("VQ2_SUBPIX", 1);
     const long big = 0x7F000000L / 4;   // the patch kernel's out-of-range sentinel must stay above every tensor
     // (a launch of <= 256 workgroups with a short depth is better off with the 64-row GEMM tiles: measured)

@@ -109,8 +109,12 @@ __device__ __forceinline__ void store_pairs(const ConvGemmParams &P, int co0, in
     }
 }
 
-template <int TPW, int NT, int BNT, bool RELU_IN>
+// CLOCK (diagnostic instantiation, scripts/clock_probe.py with VQ2_CLOCKPROBE=1): workgroups 8, 264, ... leave their lifetime in
+// shader cycles (s_memtime), in 10 ns ticks (s_memrealtime) and their MFMA count per wave.
+template <int TPW, int NT, int BNT, bool RELU_IN, bool CLOCK = false>
 __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void wino3_kernel(const ConvGemmParams P) {
+    unsigned long long clk_t0 = 0, clk_r0 = 0;
+    if constexpr (CLOCK) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
     using G = Geo<TPW, NT, BNT>;
     constexpr int B_FLOATS_T = G::B_FLOATS_T;
     constexpr int NWN = G::NWN, NTHR = G::NTHR, PW = G::PW, NPX = G::NPX, A_FLOATS = G::A_FLOATS, A_LD = G::A_LD;
@@ -264,6 +268,14 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void wino3_kernel(const ConvG
         y0 = m0 + 0.5f * (m1 + m2);
         y1 = 0.5f * (m1 - m2) - m3;
     });
+    if constexpr (CLOCK) {
+        if (P.stamps && tid == 0 && (blockIdx.x & 255) == 8 && blockIdx.x < 1024) {
+            const int slot = blockIdx.x >> 8;
+            P.stamps[slot * 4 + 0] = __builtin_amdgcn_s_memtime() - clk_t0;
+            P.stamps[slot * 4 + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+            P.stamps[slot * 4 + 2] = (unsigned long long)NCB * 3 * 16 * NT;   // MFMAs of one wave
+        }
+    }
 }
 
 // ====================================================================== 4x4 stride-2 pad-1 convolution
@@ -625,6 +637,9 @@ template <int TPW, int NT, int BNT>
 static int launch(const ConvGemmParams &P, hipStream_t s) {
     using G = Geo<TPW, NT, BNT>;
     auto kern = P.relu_in ? wino3_kernel<TPW, NT, BNT, true> : wino3_kernel<TPW, NT, BNT, false>;
+    if constexpr (TPW == 32 && NT == 2) {
+        if (P.stamps && !P.relu_in) kern = wino3_kernel<TPW, NT, BNT, false, true>;
+    }
     allow_big_lds(kern, G::LDS_BYTES);
     const unsigned nwg = (unsigned)(P.N * (P.H / G::TR) * (P.W / (2 * TPW)) * (P.Co / BNT));
     const char *name = "conv_wino";
