@@ -55,6 +55,50 @@ def test_hot_kernels_do_not_spill():
     assert seen >= 40, f"only {seen} hot kernels found in the reports"
 
 
+def test_weight_gradient_plans_and_slab_layouts_without_gpu(amd):
+    """Host side of the weight-gradient launches (pure planning code, no device): which shapes take the Winograd-domain
+    kernels, how large their slab workspaces are, and what the reduction job says about the slab layout
+    (vq2_wgrad_job.swapped: bit 0 exchanged roles, bits 1-2 the Winograd mode)."""
+    lib = amd._lib.lib
+    lib.vq2_conv_wgrad_workspace_bytes.restype = ctypes.c_size_t
+
+    def plan(cin, cout, k, stride, pad, transposed, n, h, w):
+        d = amd._lib.ConvDesc()
+        d.N, d.H, d.W, d.Ci, d.Co, d.KH, d.KW, d.stride, d.pad = n, h, w, cin, cout, k, k, stride, pad
+        d.transposed, d.ldx, d.ldy, d.Cir, d.Cor = int(transposed), cin, cout, cin, cout
+        job = amd._lib.WgradJob()
+        dummy = ctypes.c_void_p(16)
+        rc = lib.vq2_wgrad_job_init(ctypes.byref(d), dummy, dummy, dummy, ctypes.byref(job))
+        assert rc == 0, lib.vq2_last_error()
+        return lib.vq2_conv_wgrad_workspace_bytes(ctypes.byref(d)), job
+
+    # 3x3 128 -> 128 at 64x64: F(2,3) over column pairs -- K axis 12 * I, one thread column per (o, kh, i) in the reduction
+    ws, job = plan(128, 128, 3, 1, 1, False, 32, 64, 64)
+    assert (job.swapped >> 1) & 3 == 1 and job.swapped & 1 == 0 and job.taps == 9
+    assert job.n_units_w == 128 * 3 * 128 // 32 and job.n_units_b == 128 // 32
+    assert ws == (job.S * 128 * 12 * 128 + job.S * 128) * 4
+    # the same layer at 32x32 (rows are not whole 64-pixel segments): direct form, K axis 9 * I
+    ws, job = plan(128, 128, 3, 1, 1, False, 32, 32, 32)
+    assert job.swapped == 0 and job.n_units_w == 128 * 9 * 128 // 32 and ws == (job.S * 128 * 9 * 128 + job.S * 128) * 4
+    # 4x4 stride-2 64 -> 128 from 128x128, and the conv-transpose 128 -> 64 to 128x128: F(2,2) by column parity, K axis 24 * I
+    ws, job = plan(64, 128, 4, 2, 1, False, 32, 128, 128)
+    assert (job.swapped >> 1) & 3 == 2 and job.n_units_w == 128 * 8 * 64 // 32 and job.bias_splits == 0
+    assert ws == (job.S * 128 * 24 * 64 + job.S * 128) * 4
+    ws, job = plan(128, 64, 4, 2, 1, True, 32, 64, 64)
+    assert (job.swapped >> 1) & 3 == 2 and job.O == 128 and job.I == 64 and job.bias_splits == 4 * job.S
+    assert ws == (job.S * 128 * 24 * 64 + job.S * 4 * 64) * 4
+    # the ResBlock 3x3 (128 -> 32): exchanged roles + F(2,3), four 128 x 96 tiles; direct exchanged roles at 32x32
+    ws, job = plan(128, 32, 3, 1, 1, False, 32, 64, 64)
+    assert job.swapped == 1 | (3 << 1) and job.O == 128 and job.I == 32 and job.n_units_w == 128 * 3 * 32 // 32
+    assert ws == (job.S * 128 * 384 + job.S * 32) * 4
+    ws, job = plan(128, 32, 3, 1, 1, False, 32, 32, 32)
+    assert job.swapped == 1 and ws == (job.S * 128 * 288 + job.S * 32) * 4
+    # every plan keeps at least eight 32-row chunks per split and fills the resident slots
+    for args in ((128, 128, 3, 1, 1, False, 32, 64, 64), (64, 128, 4, 2, 1, False, 32, 128, 128), (128, 32, 3, 1, 1, False, 8, 128, 128)):
+        _, job = plan(*args)
+        assert 1 <= job.S <= 256
+
+
 def test_invalid_arguments_are_rejected_without_gpu(amd):
     lib = amd._lib.lib
     d = amd._lib.ConvDesc()
