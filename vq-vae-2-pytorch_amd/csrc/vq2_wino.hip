@@ -13,8 +13,8 @@
 // (measured against fp64: 1.5 - 2x the direct form's 2e-7 relative error; F(4,3) and the 2-D F(2x2,3x3) were not
 // taken: 16 accumulator sets per output tile do not fit the register file next to a 32x32 MFMA tile).
 //
-// Workgroup = TR image rows x TPW column pairs (64 pairs = 128 output pixels) x 128 output channels; wave (wm, wn) owns
-// 32 pairs x 32*NT channels for all four v (lane-local output transform).  Per 8-channel block the RAW halo patch
+// Workgroup = TR image rows x TPW column pairs (64 pairs = 128 output pixels) x 128 (or 64) output channels; wave (wm, wn)
+// owns 32 pairs x 32*NT channels for all four v (lane-local output transform).  Per 8-channel block the RAW halo patch
 // ((TR+2) x (2*TPW+2) pixels, ReLU applied) is staged once and serves the three kernel rows; a lane builds its four V
 // fragments from four patch reads.  The weight panel stays in the direct kernel's packed layout [co][(kh,kw,ci)]
 // (include/vq2.h: same ABI): the three taps of a kernel row are transformed while they are staged.
@@ -30,7 +30,6 @@ namespace wino {
 constexpr int TP = 64;             // column pairs per workgroup
 constexpr int BN = 128;            // output channels per workgroup
 constexpr int BK = 8, LDK = BK + 4;   // 48-byte LDS rows: conflict-free ds_read_b128 (vq2_conv.hip)
-constexpr int B_FLOATS = 4 * BN * LDK;
 
 // TPW: pairs per tile row (32: rows of whole 64-pixel segments, 2-row tiles; 16: 32-pixel segments, 4-row tiles -- a wave's
 // 32 pairs are then two rows).  (NT, BNT): a wave owns 32 pairs x 32*NT channels of a BNT-channel tile -- (2, 128), or (1, 64)
