@@ -493,6 +493,12 @@ def test_config5_512px_step_vs_oracle(amd):
     _step_vs_oracle(amd, O.DEFAULT, 512, 1, 32)
 
 
+def test_128px_step_vs_oracle_all_gradients(amd):
+    """128x128 images, batch 3: the bottom level is 32x32 (rows of 32 pixels: the 4-row x 16-pair geometry and the
+    64-channel tiles of the Winograd 3x3 kernel), the top level 16x16 (direct kernels only); every gradient element-wise."""
+    _step_vs_oracle(amd, O.DEFAULT, 128, 3, 67, all_elementwise=True)
+
+
 def test_config2_full_batch_step_vs_oracle(amd):
     """BASELINE configs[1] at the BENCH batch (256x256, default model, batch 32) against the CPU oracle, backward
     included: this is the launch geometry bench.py times -- the four-per-CU 128x128x16 dgrad instance (513..1,024
