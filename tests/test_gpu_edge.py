@@ -122,9 +122,9 @@ def _launched(amd, fn):
 
 
 @pytest.mark.parametrize("shape", [(2, 6, 64, 64, 128), (1, 4, 128, 72, 256), (3, 2, 64, 128, 128), (2, 6, 128, 128, 256),
-                                   (2, 8, 32, 64, 128), (1, 4, 32, 128, 64), (2, 4, 64, 64, 64), (33, 32, 32, 64, 128)])
+                                   (2, 8, 32, 64, 128), (1, 4, 32, 128, 64), (2, 4, 64, 64, 64), (33, 32, 32, 64, 128), (2, 6, 64, 32, 128)])
 def test_winograd_rows_conv_forward_and_data_gradient(amd, shape):
-    """3x3 stride-1 convolutions with >= 64 input channels, whole 64-channel output tiles and rows of whole 64-pixel segments
+    """3x3 stride-1 convolutions with >= 32 input channels, whole 64-channel output tiles and rows of whole 64-pixel segments
     (or 32-pixel ones, H % 4 == 0: the 32x32 level; the last case is a launch large enough for 128-wide tiles there) run as
     F(2,3) Winograd along the rows (csrc/vq2_wino.hip): forward with ReLU-in / bias / residual / ReLU-out
     through channel slices, data gradient with the ReLU mask and the skip gradient, against fp64 torch on the CPU.  The

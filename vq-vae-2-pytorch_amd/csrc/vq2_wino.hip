@@ -656,7 +656,7 @@ static int tune(const char *name, int dflt) {
 }  // namespace wino
 
 // Shapes the Winograd kernels take: 3x3, stride 1, pad 1, output the size of the input, whole 64-channel output tiles,
-// 8-channel input blocks (at least 64 channels), rows of whole 64-pixel segments (or 32-pixel ones with H % 4 == 0), tensors
+// 8-channel input blocks (at least 32 channels), rows of whole 64-pixel segments (or 32-pixel ones with H % 4 == 0), tensors
 // below 1 GiB (32-bit offsets with an additive out-of-range penalty); likewise the 4x4 stride-2 and sub-pixel forms.
 bool wino3_ok(const ConvGemmParams &P) {
     static const int on = wino::tune("VQ2_WINO", 1), on4 = wino::tune("VQ2_WINO_K4", 1);
@@ -673,8 +673,9 @@ bool wino3_ok(const ConvGemmParams &P) {
                (long)P.N * P.H * P.W * P.ldx * 4 < gib && (long)P.N * P.Ho * P.Wo * P.ldy * 4 < gib &&
                (long)P.N * P.Ho * P.Wo * (P.ldm > P.ldr ? P.ldm : P.ldr) * 4 < gib && (long)P.Co * P.K * 4 < gib;
     const bool rows64 = P.W % 64 == 0 && P.H % 2 == 0, rows32 = P.W % 32 == 0 && P.H % 4 == 0;
+    static const int minci = wino::tune("VQ2_WINO_MINCI", 32);   // (3x3 32 -> 128 at 64x64: 89.6 -> 74.5 us)
     return on && P.KH == 3 && P.KW == 3 && P.stride == 1 && P.pad_h == 1 && P.pad_w == 1 && P.phases == 1 &&
-           P.Ho == P.H && P.Wo == P.W && P.Hy == P.H && P.Wy == P.W && P.Ci % wino::BK == 0 && P.Ci >= 64 &&
+           P.Ho == P.H && P.Wo == P.W && P.Hy == P.H && P.Wy == P.W && P.Ci % wino::BK == 0 && P.Ci >= minci &&
            P.Co % 64 == 0 && (rows64 || rows32) && P.ldx % 4 == 0 &&
            (long)P.N * P.H * P.W * P.ldx * 4 < gib && (long)P.N * P.H * P.W * P.ldy * 4 < gib &&
            (long)P.N * P.H * P.W * (P.ldm > P.ldr ? P.ldm : P.ldr) * 4 < gib && (long)P.Co * P.K * 4 < gib;
