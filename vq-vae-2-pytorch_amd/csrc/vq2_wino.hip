@@ -687,7 +687,8 @@ int launch_wino3(const ConvGemmParams &P, hipStream_t s) {
     // 128-channel tiles where they still give every CU two workgroups; 64-channel tiles otherwise (64-channel outputs, the
     // 32x32 level)
     const long wgs128 = (long)P.N * P.H * P.W / 128 * (P.Co / 128);
-    const bool wide = P.Co % 128 == 0 && wgs128 >= 400;
+    static const int force = wino::tune("VQ2_WINO_TILE", 0);     // 1: 128-channel tiles whenever possible, 2: 64-channel tiles
+    const bool wide = P.Co % 128 == 0 && (force == 1 || (force != 2 && wgs128 >= 400));
     if (P.W % 64 == 0 && P.H % 2 == 0) return wide ? wino::launch<32, 2, 128>(P, s) : wino::launch<32, 1, 64>(P, s);
     return wide ? wino::launch<16, 2, 128>(P, s) : wino::launch<16, 1, 64>(P, s);
 }
