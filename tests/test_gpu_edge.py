@@ -517,3 +517,16 @@ def test_general_kernels_with_every_fast_path_switched_off():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider",
                         "-k", "ragged_conv_shapes or channel_slices"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_direct_forms_with_every_winograd_path_switched_off():
+    """The direct implicit-GEMM / sub-pixel / fused-ResBlock kernels that the Winograd-domain forms replaced on rows of whole
+    64-pixel segments still back every other shape (and every tensor beyond 1 GiB).  Run the model-level parity cases
+    through them in a child process (the library reads its switches once per process)."""
+    env = dict(os.environ, VQ2_WINO="0", VQ2_WINO_K4="0", VQ2_WINO_SP="0", VQ2_WWINO="0", VQ2_WWINO_K4="0", VQ2_WWINO_SW="0",
+               VQ2_RB_WINO="0")
+    parity = os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_parity.py")
+    r = subprocess.run([sys.executable, "-m", "pytest", parity, "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "full256 or 128px or tiny_vqvae_dropin"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
