@@ -266,7 +266,8 @@ def test_winograd_exchanged_roles_weight_gradient_of_the_resblock_3x3(amd, shape
         close(db.double(), br.grad, rtol=0, atol=1e-5 * float(br.grad.abs().max()), what=tag + ".db%d" % relu_in)
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 64, 128, 64), (1, 4, 128, 40, 128), (3, 12, 64, 32, 64)])
+@pytest.mark.parametrize("shape", [(2, 8, 64, 128, 64), (1, 4, 128, 40, 128), (3, 12, 64, 32, 64), (2, 8, 32, 128, 64),
+                                   (3, 16, 32, 64, 128)])
 def test_winograd_subpixel_conv_transpose_forward_and_k4s2_data_gradient(amd, shape):
     """ConvTranspose2d(k4,s2,p1) with >= 32 input channels, output channels in whole 64-tiles and input rows of whole
     64-pixel segments: every output phase is a 2-tap filter along the row and runs as F(2,2) (wino_subpixel_kernel).

@@ -473,26 +473,31 @@ static int launch_k4s2(const ConvGemmParams &P, hipStream_t s) {
 // of four.  Workgroup = 4 input rows x 32 pairs x 64 output channels of ONE phase (blockIdx -> phase fastest: the four
 // phases of a tile run next to each other on one XCD and share the patch lines in its L2); wave = one row, 32 pairs x 64
 // channels; the 5 x 65 patch of an 8-channel block serves both kernel rows a.
-namespace sp2 {
+// TPW = pairs per tile row: 32 (input rows of whole 64-pixel segments, 4-row tiles, one row per wave) or 16 (32-pixel
+// segments, 8-row tiles, two rows per wave: the 32x32 level).
 constexpr int BN2 = 64;
-constexpr int TR = 4, NPC = 65, NPX = (TR + 1) * NPC;    // patch rows x entries (2t + {0,1,2}, t < 32)
-constexpr int A_FLOATS = (NPX + 1) * LDK;
-constexpr int A_ITEMS = NPX * 2;
-constexpr int A_LD = (A_ITEMS + 255) / 256;
-constexpr int B_FLOATS2 = 3 * BN2 * LDK;
-constexpr size_t LDS_BYTES = (size_t)2 * (A_FLOATS + B_FLOATS2) * sizeof(float);
-}  // namespace sp2
+template <int TPW>
+struct Sp2 {
+    static constexpr int TR = 128 / TPW, NPC = 2 * TPW + 1, NPX = (TR + 1) * NPC;    // patch rows x entries (2t + {0,1,2})
+    static constexpr int A_FLOATS = (NPX + 1) * LDK;
+    static constexpr int A_ITEMS = NPX * 2;
+    static constexpr int A_LD = (A_ITEMS + 255) / 256;
+    static constexpr int B_FLOATS2 = 3 * BN2 * LDK;
+    static constexpr size_t LDS_BYTES = (size_t)2 * (A_FLOATS + B_FLOATS2) * sizeof(float);
+};
 
-template <bool RELU_IN>
+template <int TPW, bool RELU_IN>
 __global__ __launch_bounds__(256, 2) void wino_subpixel_kernel(const ConvGemmParams P) {
     constexpr int NT = 2;
-    using namespace sp2;
+    using G = Sp2<TPW>;
+    constexpr int TR = G::TR, NPC = G::NPC, NPX = G::NPX, A_FLOATS = G::A_FLOATS, A_ITEMS = G::A_ITEMS, A_LD = G::A_LD,
+                  B_FLOATS2 = G::B_FLOATS2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                    // [2][A_FLOATS]
     float *Bs = smem + 2 * A_FLOATS;     // [2][3][BN2][LDK]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ntn = P.Co / BN2, tw = P.W / 64, th = P.H / TR;
+    const int ntn = P.Co / BN2, tw = P.W / (2 * TPW), th = P.H / TR;
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
     const int phase = vid & 3;
     const int ph = phase >> 1, pw = phase & 1;
@@ -500,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void wino_subpixel_kernel(const ConvGemmPar
     const int n0 = (v2 % ntn) * BN2;
     const int sp = v2 / ntn;
     const int wb = sp % tw, hb = (sp / tw) % th, n = sp / (tw * th);
-    const int h0 = hb * TR, w0 = wb * 64;
+    const int h0 = hb * TR, w0 = wb * 2 * TPW;
     const int row0 = h0 - 1 + ph, col0 = w0 - 1 + pw;       // input pixel of patch entry (0, 0)
 
     const __amdgpu_buffer_rsrc_t rx =
@@ -559,7 +564,9 @@ __global__ __launch_bounds__(256, 2) void wino_subpixel_kernel(const ConvGemmPar
             for (int r = 0; r < 16; ++r) acc[v][j][r] = 0.f;
 
     const int frag_row = lane & 31, frag_k = 4 * (lane >> 5);
-    const int lane_a = (wave * NPC + 2 * frag_row) * LDK + frag_k;      // input row `wave` of the tile, pair frag_row
+    const int pi = wave * 32 + frag_row;                                 // this lane's pair of the tile
+    const int pr_l = pi / TPW, pt_l = pi - pr_l * TPW;
+    const int lane_a = (pr_l * NPC + 2 * pt_l) * LDK + frag_k;
     const int lane_b = frag_row * LDK + frag_k;
 
     auto compute = [&](const float *a, const float *b, int arow) {
@@ -613,7 +620,7 @@ __global__ __launch_bounds__(256, 2) void wino_subpixel_kernel(const ConvGemmPar
         }
     }
 
-    const int pix_lane = ((n * P.Hy + 2 * (h0 + wave) + ph) * P.Wy + 2 * (w0 + 2 * frag_row) + pw);
+    const int pix_lane = ((n * P.Hy + 2 * (h0 + pr_l) + ph) * P.Wy + 2 * (w0 + 2 * pt_l) + pw);
     store_pairs<NT>(P, n0, lane, pix_lane, [&](int j, int r, float &y0, float &y1) {
         const float m1 = acc[0][j][r], m2 = acc[1][j][r], m3 = acc[2][j][r];
         y0 = m1 + m2;
@@ -621,14 +628,16 @@ __global__ __launch_bounds__(256, 2) void wino_subpixel_kernel(const ConvGemmPar
     }, 2);
 }
 
+template <int TPW>
 static int launch_subpixel2(const ConvGemmParams &P, hipStream_t s) {
-    auto kern = P.relu_in ? wino_subpixel_kernel<true> : wino_subpixel_kernel<false>;
-    allow_big_lds(kern, sp2::LDS_BYTES);
-    const unsigned nwg = (unsigned)(4 * P.N * (P.H / sp2::TR) * (P.W / 64) * (P.Co / sp2::BN2));
+    using G = Sp2<TPW>;
+    auto kern = P.relu_in ? wino_subpixel_kernel<TPW, true> : wino_subpixel_kernel<TPW, false>;
+    allow_big_lds(kern, G::LDS_BYTES);
+    const unsigned nwg = (unsigned)(4 * P.N * (P.H / G::TR) * (P.W / (2 * TPW)) * (P.Co / BN2));
     const char *name = "conv_wino_subpixel";
-    if (prof_enabled()) name = prof_label("conv_wino_subpixel<4x64>|M=%d,N=%d,K=%d,ph4", P.M, P.Co, P.K);
+    if (prof_enabled()) name = prof_label("conv_wino_subpixel<%dx%d>|M=%d,N=%d,K=%d,ph4", G::TR, 2 * TPW, P.M, P.Co, P.K);
     ProfScope prof(name, P.flops, P.bytes, s, true);
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), sp2::LDS_BYTES, s, P);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), G::LDS_BYTES, s, P);
     return check_launch("wino_subpixel_kernel");
 }
 
@@ -663,8 +672,8 @@ bool wino3_ok(const ConvGemmParams &P) {
     const long gib = 1L << 30;
     static const int onsp = wino::tune("VQ2_WINO_SP", 1);
     if (P.phases == 4)   // sub-pixel conv-transpose: F(2,2) per output phase
-        return onsp && P.KH == 2 && P.KW == 2 && P.K == 4 * P.Ci && P.Hy == 2 * P.H && P.Wy == 2 * P.W && P.W % 64 == 0 &&
-               P.H % 4 == 0 && P.Ci % wino::BK == 0 && P.Ci >= 32 && P.Co % 64 == 0 && P.ldx % 4 == 0 &&
+        return onsp && P.KH == 2 && P.KW == 2 && P.K == 4 * P.Ci && P.Hy == 2 * P.H && P.Wy == 2 * P.W &&
+               ((P.W % 64 == 0 && P.H % 4 == 0) || (P.W % 32 == 0 && P.H % 8 == 0)) && P.Ci % wino::BK == 0 && P.Ci >= 32 && P.Co % 64 == 0 && P.ldx % 4 == 0 &&
                (long)P.N * P.H * P.W * P.ldx * 4 < gib && (long)P.N * P.Hy * P.Wy * P.ldy * 4 < gib &&
                (long)P.N * P.Hy * P.Wy * (P.ldm > P.ldr ? P.ldm : P.ldr) * 4 < gib && (long)4 * P.Co * P.K * 4 < gib;
     if (on4 && P.KH == 4 && P.KW == 4 && P.stride == 2 && P.pad_h == 1 && P.pad_w == 1 && P.phases == 1)   // F(2,2) by parity
@@ -684,7 +693,7 @@ bool wino3_ok(const ConvGemmParams &P) {
 }
 
 int launch_wino3(const ConvGemmParams &P, hipStream_t s) {
-    if (P.phases == 4) return wino::launch_subpixel2(P, s);
+    if (P.phases == 4) return P.W % 64 == 0 && P.H % 4 == 0 ? wino::launch_subpixel2<32>(P, s) : wino::launch_subpixel2<16>(P, s);
     if (P.KH == 4) return wino::launch_k4s2(P, s);
     // 128-channel tiles where they still give every CU two workgroups; 64-channel tiles otherwise (64-channel outputs, the
     // 32x32 level)
