@@ -178,10 +178,12 @@ def test_winograd_rows_conv_forward_and_data_gradient(amd, shape):
                 close(db.double(), br.grad, rtol=0, atol=1e-5 * float(br.grad.abs().max()), what=tag + ".db%d" % relu_in)
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 128, 64, 128), (1, 4, 256, 40, 256), (3, 12, 128, 32, 128)])
+@pytest.mark.parametrize("shape", [(32, 32, 128, 64, 256), (16, 16, 256, 40, 256), (52, 32, 64, 64, 128), (100, 8, 256, 64, 64),
+                                   (13, 64, 64, 32, 512)])
 def test_winograd_by_parity_k4s2_conv_forward_and_convT_data_gradient(amd, shape):
-    """4x4 stride-2 convolutions with whole 128-channel output tiles and output rows of whole 64-pixel segments run as
-    two F(2,2) filters by column parity (csrc/vq2_wino.hip): the forward with ReLU-in / bias / ReLU-out through channel
+    """4x4 stride-2 convolutions with whole 64-channel output tiles and output rows of whole 64-pixel segments (or 32-pixel
+    ones with Ho % 4 == 0), in launches of at least 400 tiles of 64 pairs x 64 channels (the first and the last case are large
+    enough for 128-wide tiles), run as two F(2,2) filters by column parity (csrc/vq2_wino.hip): the forward with ReLU-in / bias / ReLU-out through channel
     slices, and the data gradient of ConvTranspose2d(k4,s2,p1) (the same operation on dy) with its ReLU mask, vs fp64."""
     from vqvae2_amd import ops
     dev = torch.device("cuda:0")
@@ -212,7 +214,7 @@ def test_winograd_by_parity_k4s2_conv_forward_and_convT_data_gradient(amd, shape
     refg = xr.grad.permute(0, 2, 3, 1)
     close(dx.double(), refg, rtol=0, atol=5e-6 * float(refg.abs().max()), what=tag + ".dx")
     # weight / bias gradients of both layer kinds (64 gathered channels, whole 128-channel tiles): F(2,2) over column pairs
-    if ci == 64 and co % 128 == 0:
+    if ci == 64 and co % 128 == 0 and (w // 2) % 64 == 0:
         gy = t(rng.normal(11, tag + ".gy", (n, h // 2, w // 2, co))).to(dev)
         wr = wt.cpu().double().clone().requires_grad_(True)
         br = b.cpu().double().clone().requires_grad_(True)

@@ -287,32 +287,39 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void wino3_kernel(const ConvG
 // (summed over kernel rows, parities and channels before the output transform).  Same tile and pipeline as above; the
 // patch of one (kernel row, 8-channel block) holds both parities de-interleaved ([row][parity][65]: a lane's three
 // reads are then 96 bytes from its neighbour's, conflict-free) and serves two chunks.
-namespace k4 {
-constexpr int NPH = 65;                      // entries of one parity in a patch row: 2t + {0,1,2}, t < 32
-constexpr int NPX = 2 * 2 * NPH;             // [output row of the tile][parity][entry]
-constexpr int A_FLOATS = (NPX + 1) * LDK;
-constexpr int A_ITEMS = NPX * 2;
-constexpr int A_LD = (A_ITEMS + 255) / 256;
-constexpr int B3_FLOATS = 3 * BN * LDK;
-constexpr size_t LDS_BYTES = (size_t)2 * (A_FLOATS + B3_FLOATS) * sizeof(float);
-}  // namespace k4
+// TPW = pairs per tile row: 32 (output rows of whole 64-pixel segments, 2-row tiles) or 16 (32-pixel segments, 4-row tiles:
+// the 32x32 level); (NT, BNT) = (2, 128) or (1, 64) as in the 3x3 kernel.
+template <int TPW, int BNT>
+struct K4 {
+    static constexpr int TRO = TP / TPW;                  // output rows of the tile
+    static constexpr int NPH = 2 * TPW + 1;               // entries of one parity in a patch row: 2t + {0,1,2}
+    static constexpr int NPX = TRO * 2 * NPH;             // [output row of the tile][parity][entry]
+    static constexpr int A_FLOATS = (NPX + 1) * LDK;
+    static constexpr int A_ITEMS = NPX * 2;
+    static constexpr int A_LD = (A_ITEMS + 255) / 256;
+    static constexpr int B3_FLOATS = 3 * BNT * LDK;
+    static constexpr size_t LDS_BYTES = (size_t)2 * (A_FLOATS + B3_FLOATS) * sizeof(float);
+};
 
-template <bool RELU_IN>
-__global__ __launch_bounds__(256, 2) void wino_k4s2_kernel(const ConvGemmParams P) {
-    constexpr int NT = 2, NWN = 2;
-    using namespace k4;
+template <int TPW, int NT, int BNT, bool RELU_IN>
+__global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void wino_k4s2_kernel(const ConvGemmParams P) {
+    constexpr int NWN = 2;
+    static_assert(BNT == 64 * NT, "two waves along the channels");
+    using G = K4<TPW, BNT>;
+    constexpr int TRO = G::TRO, NPH = G::NPH, NPX = G::NPX, A_FLOATS = G::A_FLOATS, A_ITEMS = G::A_ITEMS, A_LD = G::A_LD,
+                  B3_FLOATS = G::B3_FLOATS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                    // [2][A_FLOATS]
-    float *Bs = smem + 2 * A_FLOATS;     // [2][3][BN][LDK]
+    float *Bs = smem + 2 * A_FLOATS;     // [2][3][BNT][LDK]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / NWN, wn = wave % NWN;
-    const int ntn = P.Co / BN, tw = P.Wo / 64, th = P.Ho / 2;
+    const int ntn = P.Co / BNT, tw = P.Wo / (2 * TPW), th = P.Ho / TRO;
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
-    const int n0 = (vid % ntn) * BN;
+    const int n0 = (vid % ntn) * BNT;
     const int sp = vid / ntn;
     const int wb = sp % tw, hb = (sp / tw) % th, n = sp / (tw * th);
-    const int h0 = hb * 2, w0 = wb * 64;      // first output row / column of the tile
+    const int h0 = hb * TRO, w0 = wb * 2 * TPW;   // first output row / column of the tile
     const int cx0 = 2 * w0 - 1;               // input column of entry 0 of the odd parity
 
     const __amdgpu_buffer_rsrc_t rx =
@@ -338,7 +345,8 @@ __global__ __launch_bounds__(256, 2) void wino_k4s2_kernel(const ConvGemmParams 
         for (int kh = 0; kh < 4; ++kh) a_vh[j] |= (cin && (unsigned)(row0 + kh) < (unsigned)P.H ? 1u : 0u) << kh;
         a_dst[j] = (ok ? px : NPX) * LDK + 4 * q;
     }
-    const int bco = tid >> 1, bq = tid & 1;
+    const bool role_b = tid < 2 * BNT;
+    const int bco = (tid & (2 * BNT - 1)) >> 1, bq = tid & 1;
     const int b_off = ((n0 + bco) * P.K + 4 * bq) * 4;
     const int b_dst = bco * LDK + 4 * bq;
     const int ci4 = P.Ci * 4, row4 = P.W * P.ldx * 4;
@@ -351,9 +359,9 @@ __global__ __launch_bounds__(256, 2) void wino_k4s2_kernel(const ConvGemmParams 
     };
     auto store_b = [&](float *b) {
         const float4 ga = as_f4(rb[0]), gb = as_f4(rb[1]);
-        *reinterpret_cast<float4 *>(b + 0 * BN * LDK + b_dst) = ga;
-        *reinterpret_cast<float4 *>(b + 1 * BN * LDK + b_dst) = add4(ga, gb);
-        *reinterpret_cast<float4 *>(b + 2 * BN * LDK + b_dst) = gb;
+        *reinterpret_cast<float4 *>(b + 0 * BNT * LDK + b_dst) = ga;
+        *reinterpret_cast<float4 *>(b + 1 * BNT * LDK + b_dst) = add4(ga, gb);
+        *reinterpret_cast<float4 *>(b + 2 * BNT * LDK + b_dst) = gb;
     };
     auto load_a = [&](int kh, int cb) {
 #pragma unroll
@@ -379,7 +387,9 @@ __global__ __launch_bounds__(256, 2) void wino_k4s2_kernel(const ConvGemmParams 
             for (int r = 0; r < 16; ++r) acc[v][j][r] = 0.f;
 
     const int frag_row = lane & 31, frag_k = 4 * (lane >> 5);
-    const int lane_a = (wm * 2 * NPH + 2 * frag_row) * LDK + frag_k;     // output row wm of the tile, pair frag_row
+    const int pi = wm * 32 + frag_row;                                   // this lane's pair of the tile
+    const int pr_l = pi / TPW, pt_l = pi - pr_l * TPW;
+    const int lane_a = (pr_l * 2 * NPH + 2 * pt_l) * LDK + frag_k;
     const int lane_b = (wn * NT * 32 + frag_row) * LDK + frag_k;
 
     auto compute = [&](const float *a, const float *b, int par) {
@@ -391,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void wino_k4s2_kernel(const ConvGemmParams 
 #pragma unroll
         for (int v = 0; v < 3; ++v)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) fb[v][j] = *reinterpret_cast<const float4 *>(b + (v * BN + j * 32) * LDK + lane_b);
+            for (int j = 0; j < NT; ++j) fb[v][j] = *reinterpret_cast<const float4 *>(b + (v * BNT + j * 32) * LDK + lane_b);
         float4 fv[3];
         fv[0] = sub4(d0, d1);
         fv[1] = d1;
@@ -408,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void wino_k4s2_kernel(const ConvGemmParams 
     load_a(0, 0);
     load_b(0, 0, 0);
     store_a(As);
-    store_b(Bs);
+    if (role_b) store_b(Bs);
     __syncthreads();
 
     // ---- main loop over patches ai = (32-channel group, kernel row, 8-channel block), two chunks (parities) per patch.
@@ -440,14 +450,14 @@ __global__ __launch_bounds__(256, 2) void wino_k4s2_kernel(const ConvGemmParams 
             __builtin_amdgcn_sched_barrier(0);
             compute(a_cur, Bs + (c & 1) * B3_FLOATS, par);
             __builtin_amdgcn_sched_barrier(0);
-            store_b(Bs + ((c + 1) & 1) * B3_FLOATS);
+            if (role_b) store_b(Bs + ((c + 1) & 1) * B3_FLOATS);
             if (par == 1) store_a(a_nxt);
             __syncthreads();
             ++c;
         }
     }
 
-    const int pix_lane = ((n * P.Ho + h0 + wm) * P.Wo + w0 + 2 * frag_row);
+    const int pix_lane = ((n * P.Ho + h0 + pr_l) * P.Wo + w0 + 2 * pt_l);
     store_pairs<NT>(P, n0 + wn * NT * 32, lane, pix_lane, [&](int j, int r, float &y0, float &y1) {
         const float m1 = acc[0][j][r], m2 = acc[1][j][r], m3 = acc[2][j][r];
         y0 = m1 + m2;
@@ -455,14 +465,16 @@ __global__ __launch_bounds__(256, 2) void wino_k4s2_kernel(const ConvGemmParams 
     });
 }
 
+template <int TPW, int NT, int BNT>
 static int launch_k4s2(const ConvGemmParams &P, hipStream_t s) {
-    auto kern = P.relu_in ? wino_k4s2_kernel<true> : wino_k4s2_kernel<false>;
-    allow_big_lds(kern, k4::LDS_BYTES);
-    const unsigned nwg = (unsigned)(P.N * (P.Ho / 2) * (P.Wo / 64) * (P.Co / BN));
+    using G = K4<TPW, BNT>;
+    auto kern = P.relu_in ? wino_k4s2_kernel<TPW, NT, BNT, true> : wino_k4s2_kernel<TPW, NT, BNT, false>;
+    allow_big_lds(kern, G::LDS_BYTES);
+    const unsigned nwg = (unsigned)(P.N * (P.Ho / G::TRO) * (P.Wo / (2 * TPW)) * (P.Co / BNT));
     const char *name = "conv_wino_k4s2";
-    if (prof_enabled()) name = prof_label("conv_wino_k4s2<2x64>|M=%d,N=%d,K=%d", P.M, P.Co, P.K);
+    if (prof_enabled()) name = prof_label("conv_wino_k4s2<%dx%d,nt%d>|M=%d,N=%d,K=%d", G::TRO, 2 * TPW, NT, P.M, P.Co, P.K);
     ProfScope prof(name, P.flops, P.bytes, s, true);
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), k4::LDS_BYTES, s, P);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), G::LDS_BYTES, s, P);
     return check_launch("wino_k4s2_kernel");
 }
 
@@ -677,8 +689,11 @@ bool wino3_ok(const ConvGemmParams &P) {
                (long)P.N * P.H * P.W * P.ldx * 4 < gib && (long)P.N * P.Hy * P.Wy * P.ldy * 4 < gib &&
                (long)P.N * P.Hy * P.Wy * (P.ldm > P.ldr ? P.ldm : P.ldr) * 4 < gib && (long)4 * P.Co * P.K * 4 < gib;
     if (on4 && P.KH == 4 && P.KW == 4 && P.stride == 2 && P.pad_h == 1 && P.pad_w == 1 && P.phases == 1)   // F(2,2) by parity
-        return 2 * P.Ho == P.H && 2 * P.Wo == P.W && P.Hy == P.Ho && P.Wy == P.Wo && P.Wo % 64 == 0 && P.Ho % 2 == 0 &&
-               P.Ci % wino::BK == 0 && P.Ci >= 32 && P.Co % wino::BN == 0 && P.ldx % 4 == 0 &&
+        return 2 * P.Ho == P.H && 2 * P.Wo == P.W && P.Hy == P.Ho && P.Wy == P.Wo &&
+               ((P.Wo % 64 == 0 && P.Ho % 2 == 0) || (P.Wo % 32 == 0 && P.Ho % 4 == 0)) &&
+               P.Ci % wino::BK == 0 && P.Ci >= 32 && P.Co % 64 == 0 && P.ldx % 4 == 0 &&
+               // (one 64-pair x 64-channel tile per CU loses to the direct 64-row tiles: 128 -> 64 at 32x32 94.5 vs 84.3 us)
+               (long)P.N * P.Ho * P.Wo / 128 * (P.Co / 64) >= 400 &&
                (long)P.N * P.H * P.W * P.ldx * 4 < gib && (long)P.N * P.Ho * P.Wo * P.ldy * 4 < gib &&
                (long)P.N * P.Ho * P.Wo * (P.ldm > P.ldr ? P.ldm : P.ldr) * 4 < gib && (long)P.Co * P.K * 4 < gib;
     const bool rows64 = P.W % 64 == 0 && P.H % 2 == 0, rows32 = P.W % 32 == 0 && P.H % 4 == 0;
@@ -694,12 +709,16 @@ bool wino3_ok(const ConvGemmParams &P) {
 
 int launch_wino3(const ConvGemmParams &P, hipStream_t s) {
     if (P.phases == 4) return P.W % 64 == 0 && P.H % 4 == 0 ? wino::launch_subpixel2<32>(P, s) : wino::launch_subpixel2<16>(P, s);
-    if (P.KH == 4) return wino::launch_k4s2(P, s);
     // 128-channel tiles where they still give every CU two workgroups; 64-channel tiles otherwise (64-channel outputs, the
     // 32x32 level)
-    const long wgs128 = (long)P.N * P.H * P.W / 128 * (P.Co / 128);
+    const long wgs128 = (long)P.N * P.Ho * P.Wo / 128 * (P.Co / 128);
     static const int force = wino::tune("VQ2_WINO_TILE", 0);     // 1: 128-channel tiles whenever possible, 2: 64-channel tiles
     const bool wide = P.Co % 128 == 0 && (force == 1 || (force != 2 && wgs128 >= 400));
+    if (P.KH == 4) {
+        if (P.Wo % 64 == 0 && P.Ho % 2 == 0)
+            return wide ? wino::launch_k4s2<32, 2, 128>(P, s) : wino::launch_k4s2<32, 1, 64>(P, s);
+        return wide ? wino::launch_k4s2<16, 2, 128>(P, s) : wino::launch_k4s2<16, 1, 64>(P, s);
+    }
     if (P.W % 64 == 0 && P.H % 2 == 0) return wide ? wino::launch<32, 2, 128>(P, s) : wino::launch<32, 1, 64>(P, s);
     return wide ? wino::launch<16, 2, 128>(P, s) : wino::launch<16, 1, 64>(P, s);
 }
