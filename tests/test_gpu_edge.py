@@ -122,7 +122,8 @@ def _launched(amd, fn):
 
 
 @pytest.mark.parametrize("shape", [(2, 6, 64, 64, 128), (1, 4, 128, 72, 256), (3, 2, 64, 128, 128), (2, 6, 128, 128, 256),
-                                   (2, 8, 32, 64, 128), (1, 4, 32, 128, 64), (2, 4, 64, 64, 64), (33, 32, 32, 64, 128), (2, 6, 64, 32, 128)])
+                                   (2, 8, 32, 64, 128), (1, 4, 32, 128, 64), (2, 4, 64, 64, 64), (33, 32, 32, 64, 128), (2, 6, 64, 32, 128),
+                                   (3, 8, 32, 128, 128)])
 def test_winograd_rows_conv_forward_and_data_gradient(amd, shape):
     """3x3 stride-1 convolutions with >= 32 input channels, whole 64-channel output tiles and rows of whole 64-pixel segments
     (or 32-pixel ones, H % 4 == 0: the 32x32 level; the last case is a launch large enough for 128-wide tiles there) run as
@@ -166,7 +167,7 @@ def test_winograd_rows_conv_forward_and_data_gradient(amd, shape):
         close(dx.double(), refg, rtol=0, atol=5e-6 * float(refg.abs().max()), what=tag + ".dx")
         # weight and bias gradient: the same transform on the reduction side (wgrad_fast_kernel<..., WINO>, whole 128-channel
         # tiles on both sides, rows of whole 64-pixel segments), with and without the fused ReLU on x, through channel slices
-        if co % 128 == 0 and ci % 128 == 0 and w % 64 == 0:
+        if co % 128 == 0 and ci % 128 == 0 and (w % 64 == 0 or (w == 32 and h % 2 == 0)):
             wr = wt.cpu().double().clone().requires_grad_(True)
             br = b.cpu().double().clone().requires_grad_(True)
             for relu_in in (True, False):
@@ -182,8 +183,8 @@ def test_winograd_rows_conv_forward_and_data_gradient(amd, shape):
                                    (13, 64, 64, 32, 512)])
 def test_winograd_by_parity_k4s2_conv_forward_and_convT_data_gradient(amd, shape):
     """4x4 stride-2 convolutions with whole 64-channel output tiles and output rows of whole 64-pixel segments (or 32-pixel
-    ones with Ho % 4 == 0), in launches of at least 400 tiles of 64 pairs x 64 channels (the first and the last case are large
-    enough for 128-wide tiles), run as two F(2,2) filters by column parity (csrc/vq2_wino.hip): the forward with ReLU-in / bias / ReLU-out through channel
+    ones with Ho % 4 == 0 and whole 128-channel tiles; the first and the last case are large enough for 128-wide tiles) run
+    as two F(2,2) filters by column parity (csrc/vq2_wino.hip): the forward with ReLU-in / bias / ReLU-out through channel
     slices, and the data gradient of ConvTranspose2d(k4,s2,p1) (the same operation on dy) with its ReLU mask, vs fp64."""
     from vqvae2_amd import ops
     dev = torch.device("cuda:0")
@@ -214,7 +215,7 @@ def test_winograd_by_parity_k4s2_conv_forward_and_convT_data_gradient(amd, shape
     refg = xr.grad.permute(0, 2, 3, 1)
     close(dx.double(), refg, rtol=0, atol=5e-6 * float(refg.abs().max()), what=tag + ".dx")
     # weight / bias gradients of both layer kinds (64 gathered channels, whole 128-channel tiles): F(2,2) over column pairs
-    if ci == 64 and co % 128 == 0 and (w // 2) % 64 == 0:
+    if ci == 64 and co % 128 == 0 and ((w // 2) % 64 == 0 or (w // 2 == 32 and (h // 2) % 2 == 0)):
         gy = t(rng.normal(11, tag + ".gy", (n, h // 2, w // 2, co))).to(dev)
         wr = wt.cpu().double().clone().requires_grad_(True)
         br = b.cpu().double().clone().requires_grad_(True)
@@ -239,7 +240,7 @@ def test_winograd_by_parity_k4s2_conv_forward_and_convT_data_gradient(amd, shape
             close(db.double(), btr.grad, rtol=0, atol=1e-5 * float(btr.grad.abs().max()), what=tag + ".dbt%d" % relu_in)
 
 
-@pytest.mark.parametrize("shape", [(2, 6, 64, 128), (1, 5, 128, 128), (3, 3, 64, 256)])
+@pytest.mark.parametrize("shape", [(2, 6, 64, 128), (1, 5, 128, 128), (3, 3, 64, 256), (2, 6, 32, 128), (3, 4, 32, 256)])
 def test_winograd_exchanged_roles_weight_gradient_of_the_resblock_3x3(amd, shape):
     """The 3x3 conv into 32 channels (ResBlock, vqvae.py:87) has its weight gradient computed with the roles of x and dy
     exchanged; on rows of whole 64-pixel segments that sum runs as F(2,3) over column pairs (wgrad_fast_kernel<..., 3>).

@@ -77,8 +77,11 @@ def test_weight_gradient_plans_and_slab_layouts_without_gpu(amd):
     assert (job.swapped >> 1) & 3 == 1 and job.swapped & 1 == 0 and job.taps == 9
     assert job.n_units_w == 128 * 3 * 128 // 32 and job.n_units_b == 128 // 32
     assert ws == (job.S * 128 * 12 * 128 + job.S * 128) * 4
-    # the same layer at 32x32 (rows are not whole 64-pixel segments): direct form, K axis 9 * I
+    # the same layer at 32x32: rows of 16 pairs, two image rows per 32-pair chunk -- still the Winograd layout
     ws, job = plan(128, 128, 3, 1, 1, False, 32, 32, 32)
+    assert (job.swapped >> 1) & 3 == 1 and ws == (job.S * 128 * 12 * 128 + job.S * 128) * 4
+    # ... and at 16x16 (neither whole 64- nor 32-pixel rows): direct form, K axis 9 * I
+    ws, job = plan(128, 128, 3, 1, 1, False, 32, 16, 16)
     assert job.swapped == 0 and job.n_units_w == 128 * 9 * 128 // 32 and ws == (job.S * 128 * 9 * 128 + job.S * 128) * 4
     # 4x4 stride-2 64 -> 128 from 128x128, and the conv-transpose 128 -> 64 to 128x128: F(2,2) by column parity, K axis 24 * I
     ws, job = plan(64, 128, 4, 2, 1, False, 32, 128, 128)
@@ -87,11 +90,13 @@ def test_weight_gradient_plans_and_slab_layouts_without_gpu(amd):
     ws, job = plan(128, 64, 4, 2, 1, True, 32, 64, 64)
     assert (job.swapped >> 1) & 3 == 2 and job.O == 128 and job.I == 64 and job.bias_splits == 4 * job.S
     assert ws == (job.S * 128 * 24 * 64 + job.S * 4 * 64) * 4
-    # the ResBlock 3x3 (128 -> 32): exchanged roles + F(2,3), four 128 x 96 tiles; direct exchanged roles at 32x32
+    # the ResBlock 3x3 (128 -> 32): exchanged roles + F(2,3), four 128 x 96 tiles (also at 32x32); direct exchanged roles at 16x16
     ws, job = plan(128, 32, 3, 1, 1, False, 32, 64, 64)
     assert job.swapped == 1 | (3 << 1) and job.O == 128 and job.I == 32 and job.n_units_w == 128 * 3 * 32 // 32
     assert ws == (job.S * 128 * 384 + job.S * 32) * 4
     ws, job = plan(128, 32, 3, 1, 1, False, 32, 32, 32)
+    assert job.swapped == 1 | (3 << 1) and ws == (job.S * 128 * 384 + job.S * 32) * 4
+    ws, job = plan(128, 32, 3, 1, 1, False, 32, 16, 16)
     assert job.swapped == 1 and ws == (job.S * 128 * 288 + job.S * 32) * 4
     # every plan keeps at least eight 32-row chunks per split and fills the resident slots
     for args in ((128, 128, 3, 1, 1, False, 32, 64, 64), (64, 128, 4, 2, 1, False, 32, 128, 128), (128, 32, 3, 1, 1, False, 8, 128, 128)):

@@ -358,16 +358,24 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
         x_two = (nu == 1 || nu == 2);
         sv = (nu == 2) ? -1.f : 1.f;
     }
+    // WINO on rows of 32 pixels (16 pairs): a 32-pair chunk is TWO image rows.  Staging rows 0..15 are the first, 16..31 the
+    // second (G_RSTEP = X_RSTEP = 8, so load j belongs to row j >> 1: a compile-time property of the load).
+    const bool two_row = WINO != 0 && P.Wo == 32;
     int g_const[G_LD], x_const[X_LD], x_iw[X_LD];
 #pragma unroll
-    for (int j = 0; j < G_LD; ++j) g_const[j] = ((g_r + j * G_RSTEP) * (WINO ? 2 : 1) * P.ldg + g_c) * 4;
+    for (int j = 0; j < G_LD; ++j) {
+        const int rj = g_r + j * G_RSTEP, r2 = two_row ? rj >> 4 : 0, tj = rj - 16 * r2;
+        g_const[j] = (WINO ? (r2 * P.Wo + 2 * tj) * P.ldg + g_c : rj * P.ldg + g_c) * 4;
+    }
 #pragma unroll
     for (int j = 0; j < X_LD; ++j) {
         const int rj = x_r + j * X_RSTEP;                    // row inside the 32-row chunk
         if constexpr (WINO) {
             constexpr int CS = WINO == 2 ? 4 : 2;            // input columns per pair
-            x_iw[j] = CS * rj;                               // + CS * pair0 + xo = input column
-            x_const[j] = (((WINO == 3 ? -kh : kh) * P.W + CS * rj) * P.ldx + ci) * 4;
+            constexpr int RS = WINO == 2 ? 2 : 1;            // input rows per row of the G grid
+            const int r2 = two_row ? rj >> 4 : 0, tj = rj - 16 * r2;
+            x_iw[j] = CS * tj;                               // + CS * pair0 + xo = input column
+            x_const[j] = (((WINO == 3 ? -kh : kh) + RS * r2) * P.W + CS * tj) * P.ldx * 4 + ci * 4;
         } else {
         x_iw[j] = rj * P.stride - P.pad + kw;                // + wo0*stride = input column
         x_const[j] = ((kh * P.W + kw + rj * P.stride) * P.ldx + ci) * 4;
@@ -394,7 +402,7 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
         for (int j = 0; j < G_LD; ++j) {
             const bool v = g_cv && (g_r + j * G_RSTEP) < rows_left;
             if constexpr (WINO == 3) {                         // (gbase carries go_a; the second pixel is go_b - go_a further)
-                const int col = 2 * (uwo + g_r + j * G_RSTEP);
+                const int col = 2 * (uwo + ((g_r + j * G_RSTEP) & (two_row ? 15 : 31)));
                 const bool va = v && (unsigned)(col + go_a) < (unsigned)P.Wo;
                 const bool vb = v && (unsigned)(col + go_b) < (unsigned)P.Wo;
                 rgv[j] = __builtin_amdgcn_raw_buffer_load_b128(rg, va ? gbase + g_const[j] : WOOB, 0, 0);
@@ -407,13 +415,16 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
         constexpr int CS = WINO == 2 ? 4 : 2;
         const int ihu = WINO == 3 ? uho + 1 : (WINO == 2 ? 2 * uho : uho) - 1;   // pad 1 (WINO 3: row shift 1 - kh)
         const int xbase = ((un * P.H + ihu) * P.W + CS * uwo) * P.ldx * 4;            // uniform
-        const bool hv = x_kv && (unsigned)(ihu + (WINO == 3 ? -kh : kh)) < (unsigned)P.H;
+        constexpr int RS = WINO == 2 ? 2 : 1;
+        const int ihk = ihu + (WINO == 3 ? -kh : kh);
+        const bool hv0 = x_kv && (unsigned)ihk < (unsigned)P.H;                       // first row of the chunk
+        const bool hv1 = two_row ? x_kv && (unsigned)(ihk + RS) < (unsigned)P.H : hv0;  // second row (two-row chunks)
         const int iwu = CS * uwo;
         const int xa = xo_a * P.ldx * 4, xb = xo_b * P.ldx * 4;
         const bool want_b = x_two || bias2u;
 #pragma unroll
         for (int j = 0; j < X_LD; ++j) {
-            const bool v = hv && (x_r + j * X_RSTEP) < rows_left;
+            const bool v = ((x_r + j * X_RSTEP) >= 16 ? hv1 : hv0) && (x_r + j * X_RSTEP) < rows_left;
             const bool va = v && (unsigned)(iwu + x_iw[j] + xo_a) < (unsigned)P.W;
             const bool vb = v && want_b && (unsigned)(iwu + x_iw[j] + xo_b) < (unsigned)P.W;
             rxv[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, va ? xbase + x_const[j] + xa : WOOB, 0, 0);
@@ -422,7 +433,8 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradParams P) {
         uwo += WG_BKR;
         if (uwo >= row_len) {
             uwo = 0;
-            if (++uho == P.Ho) { uho = 0; ++un; }
+            uho += two_row ? 2 : 1;
+            if (uho >= P.Ho) { uho = 0; ++un; }
         }
     };
     auto load_chunk = [&](int mbase) {
@@ -820,7 +832,8 @@ static WgradPlan plan_wgrad(const vq2_conv_desc *d) {
     static const int wwino = getenv("VQ2_WWINO") ? atoi(getenv("VQ2_WWINO")) : 1;
     static const int wfast = getenv("VQ2_WFAST") ? atoi(getenv("VQ2_WFAST")) : 1;
     if (wwino && wfast && !p.swapped && !d->transposed && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 &&
-        p.O % 128 == 0 && p.I % 128 == 0 && d->W % 64 == 0 && (long)d->N * d->H * d->W * d->ldx < (1L << 29) &&
+        p.O % 128 == 0 && p.I % 128 == 0 && (d->W % 64 == 0 || (d->W == 32 && d->H % 2 == 0)) &&
+        (long)d->N * d->H * d->W * d->ldx < (1L << 29) &&
         (long)d->N * d->H * d->W * d->ldy < (1L << 29)) {
         p.wino = 1;
         p.K = 12 * p.I;
@@ -830,7 +843,8 @@ static WgradPlan plan_wgrad(const vq2_conv_desc *d) {
     {   // 4x4 stride-2 conv / conv-transpose: F(2,2) by column parity over output column pairs
         const int wo = d->transposed ? d->W : d->W / 2;       // width of the G operand's grid
         if (wwino4 && wfast && !p.swapped && d->KH == 4 && d->KW == 4 && d->stride == 2 && d->pad == 1 && d->H % 2 == 0 &&
-            d->W % 2 == 0 && p.O % 128 == 0 && (p.I == 64 || p.I % 128 == 0) && wo % 64 == 0 &&
+            d->W % 2 == 0 && p.O % 128 == 0 && (p.I == 64 || p.I % 128 == 0) &&
+            (wo % 64 == 0 || (wo == 32 && (d->transposed ? d->H : d->H / 2) % 2 == 0)) &&
             (long)d->N * d->H * d->W * d->ldx < (1L << 29) &&
             (long)d->N * d->H * d->W * d->ldy * (d->transposed ? 4 : 1) < (1L << 29)) {
             p.wino = 2;
@@ -851,7 +865,8 @@ static WgradPlan plan_wgrad(const vq2_conv_desc *d) {
         const long work = po * pk;
         if (best < 0 || work < best) { best = work; p.bmo = cand[c][0]; p.bnk = cand[c][1]; }
     }
-    if (wwino3 && wfast && p.swapped && d->KH == 3 && d->pad == 1 && p.I == 32 && p.O % 128 == 0 && d->W % 64 == 0 &&
+    if (wwino3 && wfast && p.swapped && d->KH == 3 && d->pad == 1 && p.I == 32 && p.O % 128 == 0 &&
+        (d->W % 64 == 0 || (d->W == 32 && d->H % 2 == 0)) &&
         (long)d->N * d->H * d->W * d->ldx < (1L << 29) && (long)d->N * d->H * d->W * d->ldy < (1L << 29)) {
         p.wino = 3;                 // exchanged roles + F(2,3): four 128 x 96 tiles (v) of three kernel rows each
         p.K = 4 * 96;

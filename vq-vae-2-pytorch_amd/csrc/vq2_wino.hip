@@ -692,8 +692,9 @@ bool wino3_ok(const ConvGemmParams &P) {
         return 2 * P.Ho == P.H && 2 * P.Wo == P.W && P.Hy == P.Ho && P.Wy == P.Wo &&
                ((P.Wo % 64 == 0 && P.Ho % 2 == 0) || (P.Wo % 32 == 0 && P.Ho % 4 == 0)) &&
                P.Ci % wino::BK == 0 && P.Ci >= 32 && P.Co % 64 == 0 && P.ldx % 4 == 0 &&
-               // (one 64-pair x 64-channel tile per CU loses to the direct 64-row tiles: 128 -> 64 at 32x32 94.5 vs 84.3 us)
-               (long)P.N * P.Ho * P.Wo / 128 * (P.Co / 64) >= 400 &&
+               // (64-channel outputs on 32-pixel rows lose to the direct 64-row tiles -- 128 -> 64 at 32x32 and batch 32: one tile
+               //  per CU, 94.5 vs 84.3 us.  The rule must not look at the batch size: results do not depend on it.)
+               (P.Co % 128 == 0 || P.Wo % 64 == 0) &&
                (long)P.N * P.H * P.W * P.ldx * 4 < gib && (long)P.N * P.Ho * P.Wo * P.ldy * 4 < gib &&
                (long)P.N * P.Ho * P.Wo * (P.ldm > P.ldr ? P.ldm : P.ldr) * 4 < gib && (long)P.Co * P.K * 4 < gib;
     const bool rows64 = P.W % 64 == 0 && P.H % 2 == 0, rows32 = P.W % 32 == 0 && P.H % 4 == 0;
