@@ -699,6 +699,7 @@ bool wino3_ok(const ConvGemmParams &P) {
                (long)P.N * P.Ho * P.Wo * (P.ldm > P.ldr ? P.ldm : P.ldr) * 4 < gib && (long)P.Co * P.K * 4 < gib;
     const bool rows64 = P.W % 64 == 0 && P.H % 2 == 0, rows32 = P.W % 32 == 0 && P.H % 4 == 0;
     static const int minci = wino::tune("VQ2_WINO_MINCI", 32);   // (3x3 32 -> 128 at 64x64: 89.6 -> 74.5 us)
+    // (diagnostic only -- a non-zero value makes the choice, and with it the rounding, depend on the batch size)
     static const int minwg = wino::tune("VQ2_WINO_MINWG", 0);    // fewest 64-pair x 64-channel tiles worth a Winograd launch
     if ((long)P.N * P.H * P.W / 128 * (P.Co / 64) < minwg) return false;
     return on && P.KH == 3 && P.KW == 3 && P.stride == 1 && P.pad_h == 1 && P.pad_w == 1 && P.phases == 1 &&
