@@ -306,6 +306,44 @@ def test_winograd_subpixel_conv_transpose_forward_and_k4s2_data_gradient(amd, sh
     close(dx.double(), refg, rtol=0, atol=5e-6 * float(refg.abs().max()), what=tag + ".dx")
 
 
+@pytest.mark.parametrize("shape", [(4, 64, 64, 192), (5, 60, 61, 128), (3, 80, 70, 64)])
+def test_row_streaming_1x1_conv_out_of_64_channels(amd, shape):
+    """1x1 convolutions with exactly 64 input channels and 64..192 output channels on >= 16,384 pixels (the data gradient of
+    quantize_conv_b, vqvae.py:189, and the other layers fed by embed_dim) run on the row-streaming kernel
+    (conv1x1_k64_kernel): forward with ReLU-in / bias / residual / ReLU-out through channel slices, and as the data gradient
+    of a 1x1 conv into 64 channels with its ReLU mask; pixel counts that are not multiples of 32 included."""
+    from vqvae2_amd import ops
+    dev = torch.device("cuda:0")
+    n, h, w, co = shape
+    ci = 64
+    tag = "k64_%dx%dx%d" % (h, w, co)
+    wide_in = t(rng.normal(19, tag + ".in", (n, h, w, ci + 8))).to(dev)
+    x = wide_in[..., 4:4 + ci]
+    wide_out = torch.full((n, h, w, co + 8), 7.0, device=dev)
+    res = t(rng.normal(19, tag + ".res", (n, h, w, co))).to(dev)
+    wt = t(rng.uniform(19, tag + ".w", (co, ci, 1, 1), -0.2, 0.2)).to(dev)
+    b = t(rng.uniform(19, tag + ".b", (co,), -1, 1)).to(dev)
+    spec = ops.ConvSpec(False, ci, co, 1, 1, 0)
+    y, seen = _launched(amd, lambda: ops.conv_forward(spec, x, wt, b, ops.VQ2_RELU_IN | ops.VQ2_RELU_OUT, residual=res,
+                                                      out=wide_out[..., 4:4 + co]))
+    assert any(k.startswith("conv1x1_k64") for k in seen), seen
+    x64 = x.permute(0, 3, 1, 2).cpu().double()
+    ref = F.relu(F.conv2d(F.relu(x64), wt.cpu().double(), b.cpu().double()) + res.permute(0, 3, 1, 2).cpu().double()).permute(0, 2, 3, 1)
+    close(y.double(), ref, rtol=0, atol=2e-6 * float(ref.abs().max()), what=tag + ".y")
+    assert float(wide_out[..., :4].min()) == 7.0 and float(wide_out[..., 4 + co:].max()) == 7.0
+    # data gradient of Conv2d(co -> 64, 1x1): dx[.., co] = dy[.., 64] W, masked by the layer's pre-ReLU input
+    dspec = ops.ConvSpec(False, co, ci, 1, 1, 0)
+    wd = t(rng.uniform(19, tag + ".wd", (ci, co, 1, 1), -0.2, 0.2)).to(dev)
+    xin = t(rng.normal(19, tag + ".xin", (n, h, w, co))).to(dev)
+    dy = t(rng.normal(19, tag + ".dy", (n, h, w, ci))).to(dev)
+    dx, seen = _launched(amd, lambda: ops.conv_dgrad(dspec, (n, h, w, co), dy, wd, mask=xin))
+    assert any(k.startswith("conv1x1_k64") for k in seen), seen
+    xr = xin.permute(0, 3, 1, 2).cpu().double().clone().requires_grad_(True)
+    F.conv2d(F.relu(xr), wd.cpu().double(), None).backward(dy.permute(0, 3, 1, 2).cpu().double())
+    refg = xr.grad.permute(0, 2, 3, 1)
+    close(dx.double(), refg, rtol=0, atol=2e-6 * float(refg.abs().max()), what=tag + ".dx")
+
+
 def test_layout_conversion_generic_channels(amd):
     from vqvae2_amd import ops
     dev = torch.device("cuda:0")

@@ -37,7 +37,7 @@ def test_hot_kernels_do_not_spill():
     files = glob.glob(os.path.join(ROOT, "vq-vae-2-pytorch_amd", "csrc", "_obj", "*.res"))
     if not files:
         pytest.skip("no resource reports: run __graft_entry__.build() first")
-    hot = re.compile(r"conv_gemm_fast_kernel|wino3_kernel|wino_k4s2_kernel|wino_subpixel_kernel|rbw_fwd_kernel|wgrad_fast_kernel|resblock_|subpixel_conv|vq_fwd_kernel|conv_k4s2_c4|"
+    hot = re.compile(r"conv_gemm_fast_kernel|wino3_kernel|wino_k4s2_kernel|wino_subpixel_kernel|rbw_fwd_kernel|conv1x1_k64_kernel|wgrad_fast_kernel|resblock_|subpixel_conv|vq_fwd_kernel|conv_k4s2_c4|"
                      r"convT_small_mfma|vq_stats_|wgrad_reduce_batched|adam_kernel|mse_")
     seen = 0
     for f in files:

@@ -1041,6 +1041,169 @@ __global__ __launch_bounds__(256, 3) void conv_k4s2_c4_kernel(const ConvGemmPara
     }
 }
 
+// ====================================================================== 1x1 conv out of 64 channels, row-streaming
+// (the data gradient of quantize_conv_b, vqvae.py:189: 64 -> 192 channels at 64x64, and the other 1x1 layers fed by
+// embed_dim = 64.)  HBM-bound: one 256-byte row in, Co * 4 bytes out per pixel, 2 * 64 * Co FLOP.  As a GEMM tile kernel
+// (64 x 192 x 16: four chunks, then 96 stores per lane) a workgroup is a load -> compute -> store chain too short to overlap
+// with itself: 55 us stand-alone for 134 MB (2.4 TB/s), 85 us inside the step.  Here the [Co][64] panel is staged ONCE per
+// workgroup of eight waves (one per CU: 52 KB of panel + 8 x 8.7 KB of row tiles), every wave streams 32-pixel row blocks of
+// its own through a private LDS tile (no workgroup barrier in the loop; LDS operations of one wave execute in order, so the
+// tile needs no second buffer: the next block's loads are in flight while this block's MFMAs and stores run) and walks a
+// strided range of blocks.  Epilogue = the generic one (bias, ReLU mask, residual, ReLU).
+namespace k64 {
+constexpr int KC = 64, LDW = KC + 4;               // 272-byte LDS rows: conflict-free ds_read_b128
+constexpr int X_FLOATS = 32 * LDW;                 // one wave's row block
+constexpr int NWAVES = 8;                          // 512 threads: ONE workgroup per CU shares the panel, two waves per SIMD
+template <int NB> constexpr size_t lds_bytes() { return (size_t)(NB * 32 * LDW + NWAVES * X_FLOATS) * sizeof(float); }
+}  // namespace k64
+
+template <int NB, bool RELU_IN>     // NB = Co / 32 column blocks (<= 6)
+__global__ __launch_bounds__(512, 2) void conv1x1_k64_kernel(const ConvGemmParams P) {
+    using namespace k64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Ws = smem;                                        // [NB*32][LDW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *Xs = smem + NB * 32 * LDW + wave * X_FLOATS;      // this wave's [32][LDW]
+
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x), 0, P.M * P.ldx * 4, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.w), 0, P.Co * KC * 4, RSRC_FLAGS);
+    // the panel: NB * 32 rows x 16 float4
+    for (int it = tid; it < NB * 32 * 16; it += 64 * NWAVES) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, it * 16, 0, 0);
+        *reinterpret_cast<float4 *>(Ws + (it >> 4) * LDW + (it & 15) * 4) = as_f4(v);
+    }
+    // row blocks of this wave: gw, gw + nwaves, ...
+    const int nblk = (P.M + 31) / 32, gw = blockIdx.x * NWAVES + wave, nwaves = gridDim.x * NWAVES;
+    // staging: lane -> (row = (lane >> 4) + 4 j, quad = lane & 15), 8 loads per block
+    const int srow = lane >> 4, sq = lane & 15;
+    u32x4 rx8[8];
+    auto load_block = [&](int b) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int m = b * 32 + srow + 4 * j;
+            rx8[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (b < nblk && m < P.M) ? (m * P.ldx + 4 * sq) * 4 : OOB, 0, 0);
+        }
+    };
+    auto store_block = [&](float *xs) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 v = as_f4(rx8[j]);
+            *reinterpret_cast<float4 *>(xs + (srow + 4 * j) * LDW + 4 * sq) = RELU_IN ? relu4(v) : v;
+        }
+    };
+    const int ybytes = P.M * 4;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(P.y, 0, ybytes * P.ldy, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rmk =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.mask ? P.mask : P.y), 0, P.mask ? ybytes * P.ldm : 0, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.res ? P.res : P.y), 0, P.res ? ybytes * P.ldr : 0, RSRC_FLAGS);
+    const bool has_mask = P.mask != nullptr, has_res = P.res != nullptr;
+    const bool mask_first = has_mask && !P.mask_after, mask_last = has_mask && P.mask_after;
+    const int colq = lane & 31, rowq = 4 * (lane >> 5), fk = 4 * (lane >> 5);
+    const int ldy4 = P.ldy * 4, ldm4 = P.ldm * 4, ldr4 = P.ldr * 4;
+    const int relu_bits = P.relu_out ? 0 : (int)0x80000000;
+    float bv[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) bv[j] = (P.bias && j * 32 + colq < P.nbias) ? P.bias[j * 32 + colq] : 0.f;
+
+    load_block(gw);
+    __syncthreads();                       // the panel (the only workgroup-wide dependency)
+    for (int b = gw; b < nblk; b += nwaves) {
+        float *xs = Xs;
+        store_block(xs);                   // wave-private tile: program order + the LDS counter are the only sync needed
+        load_block(b + nwaves);            // next block of this wave, in flight behind the MFMAs and stores below
+        f32x16 acc[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        const float *a = xs + colq * LDW + fk;
+        const float *w = Ws + colq * LDW + fk;
+#pragma unroll
+        for (int k8 = 0; k8 < KC / 8; ++k8) {
+            const float4 fa = *reinterpret_cast<const float4 *>(a + 8 * k8);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const float4 fb = *reinterpret_cast<const float4 *>(w + j * 32 * LDW + 8 * k8);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc[j], 0, 0, 0);
+            }
+        }
+        const int m0 = b * 32;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int co4 = (j * 32 + colq) * 4;
+#pragma unroll
+            for (int rb8 = 0; rb8 < 16; rb8 += 8) {
+                int pix[8];
+                float mk[8], rs[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = rb8 + q;
+                    const int m = m0 + rowq + (r & 3) + 8 * (r >> 2);
+                    pix[q] = m < P.M ? m : -1;
+                }
+                if (has_mask) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        mk[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rmk, pix[q] >= 0 ? pix[q] * ldm4 + co4 : OOB, 0, 0));
+                }
+                if (has_res) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        rs[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, pix[q] >= 0 ? pix[q] * ldr4 + co4 : OOB, 0, 0));
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float v = acc[j][rb8 + q] + bv[j];
+                    if (mask_first) v = (mk[q] > 0.f) ? v : 0.f;
+                    if (has_res) v += rs[q];
+                    if (mask_last) v = (mk[q] > 0.f) ? v : 0.f;
+                    v = relu_floor(v, relu_bits);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, pix[q] >= 0 ? pix[q] * ldy4 + co4 : OOB, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+static bool conv_k64_ok(const ConvGemmParams &P) {
+    static const int on = getenv("VQ2_K64") ? atoi(getenv("VQ2_K64")) : 1;
+    const long gib = 1L << 30;
+    return on && P.phases == 1 && P.KH == 1 && P.KW == 1 && P.stride == 1 && P.pad_h == 0 && P.pad_w == 0 && P.Ci == 64 &&
+           P.K == 64 && P.Co % 32 == 0 && P.Co >= 64 && P.Co <= 192 && P.M >= 16384 && P.ldx % 4 == 0 &&
+           (long)P.M * P.ldx * 4 < gib && (long)P.M * P.ldy * 4 < gib && (long)P.M * (P.ldm > P.ldr ? P.ldm : P.ldr) * 4 < gib;
+}
+
+template <int NB>
+static int launch_conv_k64_nb(const ConvGemmParams &P, hipStream_t s) {
+    auto kern = P.relu_in ? conv1x1_k64_kernel<NB, true> : conv1x1_k64_kernel<NB, false>;
+    const size_t lds = k64::lds_bytes<NB>();
+    allow_big_lds(kern, lds);
+    const int nblk = (P.M + 31) / 32;
+    int grid = 256;                               // one 8-wave workgroup per CU, each wave walks nblk / 2048 row blocks
+    if (grid * k64::NWAVES > nblk) grid = (nblk + k64::NWAVES - 1) / k64::NWAVES;
+    const char *name = "conv1x1_k64";
+    if (prof_enabled()) name = prof_label("conv1x1_k64|M=%d,N=%d,K=64", P.M, P.Co);
+    ProfScope prof(name, P.flops, P.bytes, s);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * k64::NWAVES), lds, s, P);
+    return check_launch("conv1x1_k64_kernel");
+}
+
+static int launch_conv_k64(const ConvGemmParams &P, hipStream_t s) {
+    switch (P.Co / 32) {
+        case 2: return launch_conv_k64_nb<2>(P, s);
+        case 3: return launch_conv_k64_nb<3>(P, s);
+        case 4: return launch_conv_k64_nb<4>(P, s);
+        case 5: return launch_conv_k64_nb<5>(P, s);
+        default: return launch_conv_k64_nb<6>(P, s);
+    }
+}
+
 static bool conv_c4_ok(const ConvGemmParams &P) {
     const long big = 0x7F000000L / 4;
     return P.phases == 1 && P.KH == 4 && P.KW == 4 && P.stride == 2 && P.pad_h == 1 && P.pad_w == 1 && P.Ci == 4 &&
@@ -1100,6 +1263,7 @@ static int run_conv_gemm(const ConvGemmParams &P, hipStream_t s) {
                          (long)P.Co * P.K * P.phases < lim;
     static const int c4k = tune("VQ2_C4", 1);
     if (c4k && fast_ok && !legacy_stamps() && conv_c4_ok(P)) return launch_conv_c4(P, s);
+    if (fast_ok && !legacy_stamps() && conv_k64_ok(P)) return launch_conv_k64(P, s);
     if (fast_ok && !legacy_stamps() && wino3_ok(P)) {   // vq2_wino.hip
         ConvGemmParams Q = P;
         Q.stamps = g_stamps;        // (non-null only under vq2_debug_set_stamps + VQ2_CLOCKPROBE=1: the clock-probe instantiation)
