@@ -179,8 +179,8 @@ def test_winograd_rows_conv_forward_and_data_gradient(amd, shape):
                 close(db.double(), br.grad, rtol=0, atol=1e-5 * float(br.grad.abs().max()), what=tag + ".db%d" % relu_in)
 
 
-@pytest.mark.parametrize("shape", [(32, 32, 128, 64, 256), (16, 16, 256, 40, 256), (52, 32, 64, 64, 128), (100, 8, 256, 64, 64),
-                                   (13, 64, 64, 32, 512)])
+@pytest.mark.parametrize("shape", [(32, 32, 128, 64, 256), (1, 4, 256, 40, 256), (2, 16, 64, 64, 128), (2, 8, 128, 64, 64),
+                                   (13, 64, 64, 32, 512), (3, 12, 128, 32, 128)])
 def test_winograd_by_parity_k4s2_conv_forward_and_convT_data_gradient(amd, shape):
     """4x4 stride-2 convolutions with whole 64-channel output tiles and output rows of whole 64-pixel segments (or 32-pixel
     ones with Ho % 4 == 0 and whole 128-channel tiles; the first and the last case are large enough for 128-wide tiles) run
